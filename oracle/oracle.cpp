@@ -1,0 +1,558 @@
+// oracle.cpp — CPU restatement of the reference's ray-path state machine.  TEST INFRASTRUCTURE ONLY.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+// product (raytracing_amd/, librt_hip.so) never links, imports or calls it.
+//
+// Every function follows the reference op for op in IEEE binary32 (build with -ffp-contract=off,
+// no fast-math; x86-64 SSE scalar arithmetic has no excess precision), in glam 0.29.3's association
+// order (Cargo.lock:2640-2649; source not in the container — assumed semantics listed in
+// Vec3 is three scalar f32, dot = (x*x' + y*y') + z*z', normalize = v * (1/sqrt(v.v)),
+// Vec3/f32 is true division, Mat4*point = ((X*x + Y*y) + Z*z) + W).
+//
+// PINNING: the reference has no tests; the only reference-derived numbers are the four XY points of
+// python_files/tmp.py:4-9, reproduced by tests/test_oracle.py to the printed 3 decimals.  Agreement
+// with a real `cargo run` in the last ulp at the glam/rand boundary is therefore "parity unpinned"
+// (DESIGN.md §Oracle).
+//
+// The image part of orc_render (per-path value, sample accumulation) has no reference counterpart
+// (SURVEY §8 a14); it restates DESIGN.md's definition and is the only check for it.
+#include "../include/rt_hip.h"
+
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct V3 {
+    float x, y, z;
+};
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }  // Vec3 * f32
+inline V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }  // f32 * Vec3
+inline V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }  // true division
+inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline float length_squared(V3 a) { return dot(a, a); }
+inline V3 normalize(V3 a)
+{
+    float len = std::sqrt(dot(a, a));
+    float rcp = 1.0f / len;  // f32::recip
+    return a * rcp;
+}
+
+struct V4 {
+    float x, y, z, w;
+};
+inline V4 operator*(V4 a, float s) { return V4{a.x * s, a.y * s, a.z * s, a.w * s}; }
+inline V4 operator+(V4 a, V4 b) { return V4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+inline V4 operator-(V4 a, V4 b) { return V4{a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+inline V4 mul4(V4 a, V4 b) { return V4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+
+// glam Mat4: four column vectors.
+struct M4 {
+    V4 c0, c1, c2, c3;
+};
+
+inline V4 mul_vec4(const M4& m, V4 v)
+{
+    V4 r = m.c0 * v.x;
+    r = r + m.c1 * v.y;
+    r = r + m.c2 * v.z;
+    r = r + m.c3 * v.w;
+    return r;
+}
+inline M4 mul_mat4(const M4& a, const M4& b) { return M4{mul_vec4(a, b.c0), mul_vec4(a, b.c1), mul_vec4(a, b.c2), mul_vec4(a, b.c3)}; }
+inline M4 from_translation(V3 t) { return M4{V4{1, 0, 0, 0}, V4{0, 1, 0, 0}, V4{0, 0, 1, 0}, V4{t.x, t.y, t.z, 1}}; }
+inline M4 from_rotation_y(float angle)
+{
+    // glam resolves with the `libm` feature (Cargo.lock:2644-2648); libm-crate sinf/cosf are not
+    // bit-identical to glibc for every argument, exact for angle == 0 — parity unpinned otherwise.
+    float s = std::sin(angle), c = std::cos(angle);
+    return M4{V4{c, 0, -s, 0}, V4{0, 1, 0, 0}, V4{s, 0, c, 0}, V4{0, 0, 0, 1}};
+}
+inline M4 transpose(const M4& m)
+{
+    return M4{V4{m.c0.x, m.c1.x, m.c2.x, m.c3.x}, V4{m.c0.y, m.c1.y, m.c2.y, m.c3.y}, V4{m.c0.z, m.c1.z, m.c2.z, m.c3.z},
+              V4{m.c0.w, m.c1.w, m.c2.w, m.c3.w}};
+}
+// glam's cofactor inverse (scalar formulation; exact for translation-only matrices whatever the order).
+M4 inverse(const M4& m)
+{
+    float m00 = m.c0.x, m01 = m.c0.y, m02 = m.c0.z, m03 = m.c0.w;
+    float m10 = m.c1.x, m11 = m.c1.y, m12 = m.c1.z, m13 = m.c1.w;
+    float m20 = m.c2.x, m21 = m.c2.y, m22 = m.c2.z, m23 = m.c2.w;
+    float m30 = m.c3.x, m31 = m.c3.y, m32 = m.c3.z, m33 = m.c3.w;
+    float coef00 = m22 * m33 - m32 * m23, coef02 = m12 * m33 - m32 * m13, coef03 = m12 * m23 - m22 * m13;
+    float coef04 = m21 * m33 - m31 * m23, coef06 = m11 * m33 - m31 * m13, coef07 = m11 * m23 - m21 * m13;
+    float coef08 = m21 * m32 - m31 * m22, coef10 = m11 * m32 - m31 * m12, coef11 = m11 * m22 - m21 * m12;
+    float coef12 = m20 * m33 - m30 * m23, coef14 = m10 * m33 - m30 * m13, coef15 = m10 * m23 - m20 * m13;
+    float coef16 = m20 * m32 - m30 * m22, coef18 = m10 * m32 - m30 * m12, coef19 = m10 * m22 - m20 * m12;
+    float coef20 = m20 * m31 - m30 * m21, coef22 = m10 * m31 - m30 * m11, coef23 = m10 * m21 - m20 * m11;
+    V4 fac0{coef00, coef00, coef02, coef03}, fac1{coef04, coef04, coef06, coef07}, fac2{coef08, coef08, coef10, coef11};
+    V4 fac3{coef12, coef12, coef14, coef15}, fac4{coef16, coef16, coef18, coef19}, fac5{coef20, coef20, coef22, coef23};
+    V4 vec0{m10, m00, m00, m00}, vec1{m11, m01, m01, m01}, vec2{m12, m02, m02, m02}, vec3{m13, m03, m03, m03};
+    V4 inv0 = (mul4(vec1, fac0) - mul4(vec2, fac1)) + mul4(vec3, fac2);
+    V4 inv1 = (mul4(vec0, fac0) - mul4(vec2, fac3)) + mul4(vec3, fac4);
+    V4 inv2 = (mul4(vec0, fac1) - mul4(vec1, fac3)) + mul4(vec3, fac5);
+    V4 inv3 = (mul4(vec0, fac2) - mul4(vec1, fac4)) + mul4(vec2, fac5);
+    V4 sa{1, -1, 1, -1}, sb{-1, 1, -1, 1};
+    M4 inv{mul4(inv0, sa), mul4(inv1, sb), mul4(inv2, sa), mul4(inv3, sb)};
+    V4 col0{inv.c0.x, inv.c1.x, inv.c2.x, inv.c3.x};
+    V4 d0 = mul4(m.c0, col0);
+    float det = ((d0.x + d0.y) + d0.z) + d0.w;
+    float rcp = 1.0f / det;
+    return M4{inv.c0 * rcp, inv.c1 * rcp, inv.c2 * rcp, inv.c3 * rcp};
+}
+inline V3 transform_point3(const M4& m, V3 p)
+{
+    V4 r = m.c0 * p.x;
+    r = m.c1 * p.y + r;
+    r = m.c2 * p.z + r;
+    r = m.c3 + r;
+    return v3(r.x, r.y, r.z);
+}
+inline V3 transform_vector3(const M4& m, V3 p)
+{
+    V4 r = m.c0 * p.x;
+    r = m.c1 * p.y + r;
+    r = m.c2 * p.z + r;
+    return v3(r.x, r.y, r.z);
+}
+
+struct Ray {
+    V3 origin, direction;
+    float current_ior;
+};
+struct Hit {
+    float t;
+    V3 point, normal;
+    bool front_face;
+    uint32_t mat_kind;
+    float mat_param;
+};
+
+// primitives/sphere.rs:12-74 — returns the FIRST element of the hit list (scene.rs:55 takes hits.first()).
+inline bool sphere_first_hit(V3 center, float radius, const Ray& ray, float t_min, float t_max, Hit& out)
+{
+    V3 oc = ray.origin - center;
+    float a = length_squared(ray.direction);
+    float half_b = dot(oc, ray.direction);
+    float c = length_squared(oc) - radius * radius;
+    float discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0f) return false;
+    float sqrtd = std::sqrt(discriminant);
+    float t1 = (-half_b - sqrtd) / a;
+    float t = 0;
+    bool have = false;
+    if (t1 > t_min && t1 < t_max) {
+        t = t1;
+        have = true;
+    } else if (discriminant > 1e-6f) {
+        float t2 = (-half_b + sqrtd) / a;
+        if (t2 > t_min && t2 < t_max) {
+            t = t2;
+            have = true;
+        }
+    }
+    if (!have) return false;
+    V3 point = ray.origin + t * ray.direction;
+    V3 outward = (point - center) / radius;
+    bool front = dot(ray.direction, outward) < 0.0f;
+    out.t = t;
+    out.point = point;
+    out.normal = front ? outward : -outward;
+    out.front_face = front;
+    return true;
+}
+
+// primitives/plane.rs:12-54
+inline bool plane_first_hit(V3 ppoint, V3 normal, const Ray& ray, float t_min, float t_max, Hit& out)
+{
+    float denom = dot(normal, ray.direction);
+    if (std::fabs(denom) < 1e-6f) return false;
+    float t = dot(ppoint - ray.origin, normal) / denom;
+    if (t < t_min || t_max < t) return false;
+    V3 point = ray.origin + t * ray.direction;
+    bool front = dot(ray.direction, normal) < 0.0f;
+    out.t = t;
+    out.point = point;
+    out.normal = front ? normal : -normal;
+    out.front_face = front;
+    return true;
+}
+
+struct Object {  // Transform(Box<primitive>) — transform.rs:4-17, object_config.rs:16-30
+    uint32_t shape;
+    uint32_t mat_kind;
+    float mat_param;
+    float radius;
+    V3 normal;
+    M4 transform, inverse_transform, inverse_transpose;
+};
+
+Object build_object(const RtObject& o)
+{
+    Object r{};
+    r.shape = o.shape;
+    r.mat_kind = o.material_kind;
+    r.mat_param = o.material_param;
+    r.radius = o.shape_param[0];
+    r.normal = v3(o.shape_param[0], o.shape_param[1], o.shape_param[2]);
+    M4 translation = from_translation(v3(o.position[0], o.position[1], o.position[2]));
+    const float rads_per_deg = 3.14159265358979323846f / 180.0f;  // f32::to_radians
+    M4 rotation = from_rotation_y(o.rotation_y_deg * rads_per_deg);
+    r.transform = mul_mat4(translation, rotation);
+    r.inverse_transform = inverse(r.transform);
+    r.inverse_transpose = transpose(r.inverse_transform);
+    return r;
+}
+
+// transform.rs:20-51 around the wrapped primitive (local centre / local plane point = origin:
+// shape_config.rs:56-60, 69-73).
+inline bool object_first_hit(const Object& ob, const Ray& ray, float t_min, float t_max, Hit& out)
+{
+    Ray local;
+    local.origin = transform_point3(ob.inverse_transform, ray.origin);
+    local.direction = transform_vector3(ob.inverse_transform, ray.direction);
+    local.current_ior = ray.current_ior;
+    bool ok = (ob.shape == RT_SHAPE_SPHERE) ? sphere_first_hit(v3(0, 0, 0), ob.radius, local, t_min, t_max, out)
+                                            : plane_first_hit(v3(0, 0, 0), ob.normal, local, t_min, t_max, out);
+    if (!ok) return false;
+    out.point = transform_point3(ob.transform, out.point);
+    out.normal = normalize(transform_vector3(ob.inverse_transpose, out.normal));
+    out.mat_kind = ob.mat_kind;
+    out.mat_param = ob.mat_param;
+    return true;
+}
+
+// scene.rs:9-11
+inline V3 reflect(V3 incident, V3 normal) { return incident - 2.0f * dot(incident, normal) * normal; }
+
+// scene.rs:14-27 (the println! on total internal reflection, scene.rs:19, is dropped)
+inline bool refract(V3 incident, V3 normal, float ior_ratio, V3& out)
+{
+    float cos_theta = std::fmin(dot(-incident, normal), 1.0f);
+    float sin_theta_squared = 1.0f - cos_theta * cos_theta;
+    if (ior_ratio * ior_ratio * sin_theta_squared > 1.0f) return false;
+    V3 perp = ior_ratio * (incident + cos_theta * normal);
+    V3 parallel = -std::sqrt(std::fabs(1.0f - length_squared(perp))) * normal;
+    out = normalize(perp + parallel);
+    return true;
+}
+
+// Counter-based replacement for rand::thread_rng().gen::<f32>() (scene.rs:88): Philox4x32-10 keyed by
+// the seed, counter = (path id lo, path id hi, bounce, tag); rand 0.8 `Standard` f32 mapping
+// (next_u32() >> 8) * 2^-24.
+inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+inline float uniform01(uint64_t seed, uint64_t path_id, uint32_t bounce)
+{
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t c0 = (uint32_t)path_id, c1 = (uint32_t)(path_id >> 32), c2 = bounce, c3 = 0x52415953u;
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+}
+
+struct Scene {
+    std::vector<Object> objects;
+};
+
+// One path of Scene::simulate_rays (scene.rs:43-103).  Returns the number of bounce-loop iterations
+// executed (the "ray segments" of the Mrays/s metric).
+struct PathOut {
+    float* points;            // [(max_bounces+1)*3] or null
+    uint32_t* n_points;       // or null
+    RtBounceRecord* records;  // [max_bounces] or null
+};
+uint32_t trace_path(const Scene& sc, Ray ray, RtSettings st, uint64_t seed, uint64_t path_id, const PathOut& po,
+                    bool* escaped, V3* final_dir)
+{
+    uint32_t np = 0, segments = 0;
+    auto push = [&](V3 p) {
+        if (po.points) {
+            po.points[np * 3 + 0] = p.x;
+            po.points[np * 3 + 1] = p.y;
+            po.points[np * 3 + 2] = p.z;
+        }
+        ++np;
+    };
+    push(ray.origin);
+    *escaped = false;
+    for (uint32_t bounce = 0; bounce < st.max_bounces; ++bounce) {
+        ++segments;
+        float t_closest = std::numeric_limits<float>::infinity();
+        bool have = false;
+        Hit closest{};
+        int32_t closest_id = -1;
+        for (size_t k = 0; k < sc.objects.size(); ++k) {
+            Hit h;
+            if (object_first_hit(sc.objects[k], ray, 0.001f, t_closest, h)) {
+                if (h.t < t_closest) {
+                    t_closest = h.t;
+                    closest = h;
+                    closest_id = (int32_t)k;
+                    have = true;
+                }
+            }
+        }
+        RtBounceRecord rec;
+        std::memset(&rec, 0, sizeof rec);
+        if (have) {
+            push(closest.point);
+            if (closest.mat_kind == RT_MAT_MIRROR) {
+                ray.direction = reflect(ray.direction, closest.normal);
+            } else if (closest.mat_kind == RT_MAT_GLASS) {
+                float n1 = ray.current_ior;
+                float n2 = closest.front_face ? closest.mat_param : 1.0f;
+                float ior_ratio = n1 / n2;
+                V3 refr;
+                if (refract(ray.direction, closest.normal, ior_ratio, refr)) {
+                    ray.direction = refr;
+                    ray.current_ior = n2;
+                } else {
+                    ray.direction = reflect(ray.direction, closest.normal);
+                }
+            } else {  // HalfMirror
+                if (uniform01(seed, path_id, bounce) < closest.mat_param) ray.direction = reflect(ray.direction, closest.normal);
+            }
+            ray.origin = closest.point + ray.direction * 0.001f;
+            if (po.records) {
+                rec.obj_id = closest_id;
+                rec.t = closest.t;
+                rec.point[0] = closest.point.x; rec.point[1] = closest.point.y; rec.point[2] = closest.point.z;
+                rec.normal[0] = closest.normal.x; rec.normal[1] = closest.normal.y; rec.normal[2] = closest.normal.z;
+                rec.front_face = closest.front_face ? 1u : 0u;
+                rec.dir_out[0] = ray.direction.x; rec.dir_out[1] = ray.direction.y; rec.dir_out[2] = ray.direction.z;
+                rec.ior_out = ray.current_ior;
+                po.records[bounce] = rec;
+            }
+        } else {
+            V3 far = ray.origin + ray.direction * st.infinity_distance;
+            push(far);
+            if (po.records) {
+                rec.obj_id = -1;
+                rec.t = std::numeric_limits<float>::infinity();
+                rec.point[0] = far.x; rec.point[1] = far.y; rec.point[2] = far.z;
+                rec.ior_out = ray.current_ior;
+                po.records[bounce] = rec;
+            }
+            *escaped = true;
+            break;
+        }
+    }
+    if (po.n_points) *po.n_points = np;
+    *final_dir = ray.direction;
+    return segments;
+}
+
+// scene_config.rs:60-108 for one cell (i = cell / count_v, j = cell % count_v).
+Ray generate_ray(const RtRayGenerator& g, uint64_t cell)
+{
+    uint32_t i = (uint32_t)(cell / g.count_v), j = (uint32_t)(cell % g.count_v);
+    V3 a = v3(g.a[0], g.a[1], g.a[2]);
+    V3 u_step = v3(g.u[0], g.u[1], g.u[2]) / (float)g.count_u;
+    V3 v_step = v3(g.v[0], g.v[1], g.v[2]) / (float)g.count_v;
+    Ray r;
+    r.current_ior = g.current_ior;
+    if (g.kind == RT_GEN_PARALLEL_GRID) {
+        V3 dir = normalize(v3(g.direction[0], g.direction[1], g.direction[2]));
+        r.origin = (a + ((float)i * u_step)) + ((float)j * v_step);
+        r.direction = dir;
+    } else {
+        V3 corner = v3(g.corner[0], g.corner[1], g.corner[2]);
+        V3 target = (corner + ((float)i * u_step)) + ((float)j * v_step);
+        r.origin = a;
+        r.direction = normalize(target - a);
+    }
+    return r;
+}
+
+// DESIGN.md "path value": a path that escapes contributes sky(final direction); one that exhausts
+// max_bounces contributes 0.  sky(d): w = 0.5*(d.y + 1); rgb = (1-w)*white + w*(0.5, 0.7, 1.0).
+inline V3 sky(V3 d)
+{
+    float w = 0.5f * (d.y + 1.0f);
+    float k = 1.0f - w;
+    return v3(k + w * 0.5f, k + w * 0.7f, k + w);
+}
+
+}  // namespace
+
+extern "C" {
+
+struct orc_scene {
+    Scene sc;
+};
+
+orc_scene* orc_scene_create(const RtObject* objects, uint64_t n)
+{
+    orc_scene* s = new orc_scene;
+    s->sc.objects.reserve(n);
+    for (uint64_t k = 0; k < n; ++k) s->sc.objects.push_back(build_object(objects[k]));
+    return s;
+}
+void orc_scene_destroy(orc_scene* s) { delete s; }
+
+// Mirrors rt_hip_simulate (include/rt_hip.h).  Returns total segments.
+uint64_t orc_simulate(const orc_scene* s, const RtRay* rays, uint64_t n_rays, RtSettings st, uint64_t seed,
+                      uint64_t ray_id_base, float* out_points, uint32_t* out_n_points, RtBounceRecord* out_records)
+{
+    uint64_t total = 0;
+    const uint64_t stride = (uint64_t)st.max_bounces + 1;
+    if (out_records) std::memset(out_records, 0, sizeof(RtBounceRecord) * n_rays * st.max_bounces);
+    if (out_points) std::memset(out_points, 0, sizeof(float) * 3 * stride * n_rays);
+    for (uint64_t r = 0; r < n_rays; ++r) {
+        Ray ray;
+        ray.origin = v3(rays[r].origin[0], rays[r].origin[1], rays[r].origin[2]);
+        ray.direction = v3(rays[r].direction[0], rays[r].direction[1], rays[r].direction[2]);
+        ray.current_ior = rays[r].current_ior;
+        PathOut po{out_points ? out_points + r * stride * 3 : nullptr, out_n_points ? out_n_points + r : nullptr,
+                   out_records ? out_records + r * st.max_bounces : nullptr};
+        bool esc;
+        V3 fd;
+        total += trace_path(s->sc, ray, st, seed, ray_id_base + r, po, &esc, &fd);
+    }
+    return total;
+}
+
+// Expand a generator into rays, in the reference's order (scene_config.rs:74-107).
+void orc_generate_rays(const RtRayGenerator* gen, uint64_t cell_begin, uint64_t cell_count, uint64_t cell_step, RtRay* out)
+{
+    for (uint64_t m = 0; m < cell_count; ++m) {
+        Ray r = generate_ray(*gen, cell_begin + m * cell_step);
+        out[m].origin[0] = r.origin.x; out[m].origin[1] = r.origin.y; out[m].origin[2] = r.origin.z;
+        out[m].direction[0] = r.direction.x; out[m].direction[1] = r.direction.y; out[m].direction[2] = r.direction.z;
+        out[m].current_ior = r.current_ior;
+    }
+}
+
+static void render_range(const orc_scene* s, const RtRayGenerator* gen, uint32_t spp, RtSettings st, uint64_t seed,
+                         uint64_t cell_begin, uint64_t cell_step, uint64_t m0, uint64_t m1, float* fb, int32_t* first_id,
+                         float* first_t, uint32_t* seg_count, uint64_t* total)
+{
+    uint64_t tot = 0;
+    std::vector<RtBounceRecord> recs(st.max_bounces ? st.max_bounces : 1);
+    for (uint64_t m = m0; m < m1; ++m) {
+        uint64_t cell = cell_begin + m * cell_step;
+        Ray ray = generate_ray(*gen, cell);
+        V3 acc = v3(0, 0, 0);
+        uint32_t segs = 0;
+        for (uint32_t sidx = 0; sidx < spp; ++sidx) {
+            bool esc;
+            V3 fd;
+            PathOut po{nullptr, nullptr, (sidx == 0) ? recs.data() : nullptr};
+            if (sidx == 0) std::memset(recs.data(), 0, sizeof(RtBounceRecord) * recs.size());
+            segs += trace_path(s->sc, ray, st, seed, cell * (uint64_t)spp + sidx, po, &esc, &fd);
+            if (sidx == 0) {
+                if (first_id) first_id[m] = st.max_bounces ? recs[0].obj_id : -1;
+                if (first_t) first_t[m] = st.max_bounces ? recs[0].t : std::numeric_limits<float>::infinity();
+            }
+            V3 val = esc ? sky(fd) : v3(0, 0, 0);
+            acc = acc + val;
+        }
+        float fs = (float)spp;
+        fb[m * 3 + 0] = acc.x / fs;
+        fb[m * 3 + 1] = acc.y / fs;
+        fb[m * 3 + 2] = acc.z / fs;
+        if (seg_count) seg_count[m] = segs;
+        tot += segs;
+    }
+    *total = tot;
+}
+
+// Mirrors rt_hip_render.  n_threads <= 1: the reference's single-threaded loop; otherwise cells are
+// split into contiguous ranges over std::thread workers (results identical: cells are independent).
+uint64_t orc_render(const orc_scene* s, const RtRayGenerator* gen, uint32_t spp, RtSettings st, uint64_t seed,
+                    uint64_t cell_begin, uint64_t cell_count, uint64_t cell_step, float* fb, int32_t* first_id,
+                    float* first_t, uint32_t* seg_count, uint32_t n_threads)
+{
+    if (n_threads <= 1) {
+        uint64_t tot = 0;
+        render_range(s, gen, spp, st, seed, cell_begin, cell_step, 0, cell_count, fb, first_id, first_t, seg_count, &tot);
+        return tot;
+    }
+    std::vector<std::thread> th;
+    std::vector<uint64_t> tots(n_threads, 0);
+    // dynamic chunking so uneven cells do not idle threads
+    std::atomic<uint64_t> next{0};
+    const uint64_t chunk = 64;
+    for (uint32_t t = 0; t < n_threads; ++t) {
+        th.emplace_back([&, t]() {
+            for (;;) {
+                uint64_t m0 = next.fetch_add(chunk);
+                if (m0 >= cell_count) break;
+                uint64_t m1 = m0 + chunk < cell_count ? m0 + chunk : cell_count;
+                uint64_t part = 0;
+                render_range(s, gen, spp, st, seed, cell_begin, cell_step, m0, m1, fb, first_id, first_t, seg_count, &part);
+                tots[t] += part;
+            }
+        });
+    }
+    for (auto& x : th) x.join();
+    uint64_t tot = 0;
+    for (auto v : tots) tot += v;
+    return tot;
+}
+
+// Unit-level entry points so tests can pin individual functions (SURVEY §4 KAT list).
+int orc_sphere_first_hit(const float center[3], float radius, const RtRay* ray, float t_min, float t_max, float* t,
+                         float point[3], float normal[3], uint32_t* front_face)
+{
+    Ray r{v3(ray->origin[0], ray->origin[1], ray->origin[2]), v3(ray->direction[0], ray->direction[1], ray->direction[2]),
+          ray->current_ior};
+    Hit h;
+    if (!sphere_first_hit(v3(center[0], center[1], center[2]), radius, r, t_min, t_max, h)) return 0;
+    *t = h.t;
+    point[0] = h.point.x; point[1] = h.point.y; point[2] = h.point.z;
+    normal[0] = h.normal.x; normal[1] = h.normal.y; normal[2] = h.normal.z;
+    *front_face = h.front_face;
+    return 1;
+}
+int orc_plane_first_hit(const float ppoint[3], const float pnormal[3], const RtRay* ray, float t_min, float t_max, float* t,
+                        float point[3], float normal[3], uint32_t* front_face)
+{
+    Ray r{v3(ray->origin[0], ray->origin[1], ray->origin[2]), v3(ray->direction[0], ray->direction[1], ray->direction[2]),
+          ray->current_ior};
+    Hit h;
+    if (!plane_first_hit(v3(ppoint[0], ppoint[1], ppoint[2]), v3(pnormal[0], pnormal[1], pnormal[2]), r, t_min, t_max, h)) return 0;
+    *t = h.t;
+    point[0] = h.point.x; point[1] = h.point.y; point[2] = h.point.z;
+    normal[0] = h.normal.x; normal[1] = h.normal.y; normal[2] = h.normal.z;
+    *front_face = h.front_face;
+    return 1;
+}
+void orc_reflect(const float i[3], const float n[3], float out[3])
+{
+    V3 r = reflect(v3(i[0], i[1], i[2]), v3(n[0], n[1], n[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+int orc_refract(const float i[3], const float n[3], float ior_ratio, float out[3])
+{
+    V3 r;
+    if (!refract(v3(i[0], i[1], i[2]), v3(n[0], n[1], n[2]), ior_ratio, r)) return 0;
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+    return 1;
+}
+float orc_uniform01(uint64_t seed, uint64_t path_id, uint32_t bounce) { return uniform01(seed, path_id, bounce); }
+// transform / inverse of T(position)*R_y(deg) as 16 column-major floats each (for the exactness test).
+void orc_object_matrices(const RtObject* o, float transform[16], float inverse_transform[16])
+{
+    Object ob = build_object(*o);
+    std::memcpy(transform, &ob.transform, 64);
+    std::memcpy(inverse_transform, &ob.inverse_transform, 64);
+}
+
+}  // extern "C"

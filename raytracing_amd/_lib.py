@@ -1,0 +1,76 @@
+"""Loader for librt_hip.so (the C-ABI library declared in include/rt_hip.h).
+
+There is no fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+_LIB = None
+
+# every symbol include/rt_hip.h declares
+EXPORTS = [
+    "rt_hip_init",
+    "rt_hip_shutdown",
+    "rt_hip_last_error",
+    "rt_hip_scene_create",
+    "rt_hip_scene_destroy",
+    "rt_hip_scene_counts",
+    "rt_hip_simulate",
+    "rt_hip_simulate_dev",
+    "rt_hip_render",
+    "rt_hip_render_dev",
+    "rt_hip_set_scan_mode",
+]
+
+
+class RtHipError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"rt_hip error {code}: {text}")
+        self.code = code
+
+
+def lib():
+    """dlopen librt_hip.so and declare prototypes. Does not touch the GPU."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C raytracing_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    L.rt_hip_init.argtypes = [C.c_int]
+    L.rt_hip_init.restype = C.c_int
+    L.rt_hip_shutdown.argtypes = []
+    L.rt_hip_shutdown.restype = None
+    L.rt_hip_last_error.argtypes = []
+    L.rt_hip_last_error.restype = C.c_char_p
+    L.rt_hip_scene_create.argtypes = [vp, u64, C.POINTER(vp)]
+    L.rt_hip_scene_create.restype = C.c_int
+    L.rt_hip_scene_destroy.argtypes = [vp]
+    L.rt_hip_scene_destroy.restype = None
+    L.rt_hip_scene_counts.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.rt_hip_scene_counts.restype = C.c_int
+    L.rt_hip_simulate.argtypes = [vp, vp, u64, abi.RtSettings, u64, u64, vp, vp, vp]
+    L.rt_hip_simulate.restype = C.c_int
+    L.rt_hip_simulate_dev.argtypes = [vp, vp, u64, abi.RtSettings, u64, u64, vp, vp, vp, vp, vp]
+    L.rt_hip_simulate_dev.restype = C.c_int
+    L.rt_hip_render.argtypes = [vp, C.POINTER(abi.RtRayGenerator), u32, abi.RtSettings, u64, u64, u64, u64, vp, vp, vp, vp,
+                                C.POINTER(u64)]
+    L.rt_hip_render.restype = C.c_int
+    L.rt_hip_render_dev.argtypes = [vp, C.POINTER(abi.RtRayGenerator), u32, abi.RtSettings, u64, u64, u64, u64, vp, vp, vp,
+                                    vp, vp, vp]
+    L.rt_hip_render_dev.restype = C.c_int
+    L.rt_hip_set_scan_mode.argtypes = [C.c_int]
+    L.rt_hip_set_scan_mode.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RtHipError(rc, lib().rt_hip_last_error().decode("utf-8", "replace"))

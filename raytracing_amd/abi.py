@@ -1,0 +1,64 @@
+"""ctypes / numpy mirrors of include/rt_hip.h (one-to-one, tightly packed 32-bit fields)."""
+import ctypes as C
+
+import numpy as np
+
+RT_MAT_MIRROR, RT_MAT_GLASS, RT_MAT_HALF_MIRROR = 0, 1, 2
+RT_SHAPE_SPHERE, RT_SHAPE_PLANE = 0, 1
+RT_GEN_PARALLEL_GRID, RT_GEN_PROJECTOR = 0, 1
+
+RT_OK, RT_ERR_INVALID, RT_ERR_UNSUPPORTED, RT_ERR_HIP, RT_ERR_NOT_INIT = 0, -1, -2, -3, -4
+
+# numpy structured dtypes (arrays of these are passed by pointer)
+OBJECT_DTYPE = np.dtype(
+    [
+        ("shape", "<u4"),
+        ("material_kind", "<u4"),
+        ("material_param", "<f4"),
+        ("rotation_y_deg", "<f4"),
+        ("position", "<f4", (3,)),
+        ("shape_param", "<f4", (4,)),
+    ]
+)
+RAY_DTYPE = np.dtype([("origin", "<f4", (3,)), ("direction", "<f4", (3,)), ("current_ior", "<f4")])
+RECORD_DTYPE = np.dtype(
+    [
+        ("obj_id", "<i4"),
+        ("t", "<f4"),
+        ("point", "<f4", (3,)),
+        ("normal", "<f4", (3,)),
+        ("front_face", "<u4"),
+        ("dir_out", "<f4", (3,)),
+        ("ior_out", "<f4"),
+    ]
+)
+assert OBJECT_DTYPE.itemsize == 44 and RAY_DTYPE.itemsize == 28 and RECORD_DTYPE.itemsize == 52
+
+
+class RtSettings(C.Structure):
+    _fields_ = [("infinity_distance", C.c_float), ("max_bounces", C.c_uint32)]
+
+
+class RtRayGenerator(C.Structure):
+    _fields_ = [
+        ("kind", C.c_uint32),
+        ("count_u", C.c_uint32),
+        ("count_v", C.c_uint32),
+        ("current_ior", C.c_float),
+        ("a", C.c_float * 3),
+        ("corner", C.c_float * 3),
+        ("u", C.c_float * 3),
+        ("v", C.c_float * 3),
+        ("direction", C.c_float * 3),
+    ]
+
+
+assert C.sizeof(RtRayGenerator) == 76 and C.sizeof(RtSettings) == 8
+
+
+def ptr(arr, ctype=C.c_void_p):
+    """Pointer to a C-contiguous numpy array (or None)."""
+    if arr is None:
+        return None
+    assert arr.flags["C_CONTIGUOUS"]
+    return arr.ctypes.data_as(ctype)

@@ -1,0 +1,445 @@
+// rt_capi.cpp — C-ABI entry points of librt_hip.so (include/rt_hip.h): context, scene flattening
+// (the GPU-side counterpart of SceneConfig -> Scene, scene_config.rs:22-52 + object_config.rs:16-30),
+// buffer management and kernel launches.  There is no CPU fallback: every entry point either runs the
+// gfx950 kernels or fails with an error code.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rt_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_mu;
+
+struct Context {
+    bool ready = false;
+    int device = -1;
+    int n_cu = 0;
+    unsigned int* counters = nullptr;  // ring of per-launch work counters
+    unsigned next_counter = 0;
+};
+Context g_ctx;
+constexpr unsigned kCounterRing = 1024;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+int fail_hip(hipError_t e, const char* what)
+{
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return RT_ERR_HIP;
+}
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t e_ = (expr);                         \
+        if (e_ != hipSuccess) return fail_hip(e_, #expr); \
+    } while (0)
+
+template <class T>
+hipError_t upload(const std::vector<T>& v, const T** out)
+{
+    *out = nullptr;
+    size_t n = v.size() ? v.size() : 1;
+    T* d = nullptr;
+    hipError_t e = hipMalloc((void**)&d, n * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (v.size()) {
+        e = hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d);
+            return e;
+        }
+    }
+    *out = d;
+    return hipSuccess;
+}
+
+}  // namespace
+
+struct rt_scene {
+    rt::DevScene dev{};
+    std::vector<void*> allocations;
+};
+
+namespace {
+
+void free_scene(rt_scene* s)
+{
+    if (!s) return;
+    for (void* p : s->allocations) (void)hipFree(p);
+    delete s;
+}
+
+// scene_config.rs:70-72 / 96-97 and the ParallelGrid normalisation (scene_config.rs:72), in IEEE f32.
+rt::DevGen make_dev_gen(const RtRayGenerator& g)
+{
+    rt::DevGen d{};
+    d.kind = g.kind;
+    d.count_u = g.count_u;
+    d.count_v = g.count_v;
+    d.current_ior = g.current_ior;
+    const float cu = (float)g.count_u, cv = (float)g.count_v;
+    for (int k = 0; k < 3; ++k) {
+        d.a[k] = g.a[k];
+        d.corner[k] = g.corner[k];
+        d.u_step[k] = g.u[k] / cu;
+        d.v_step[k] = g.v[k] / cv;
+    }
+    const float x = g.direction[0], y = g.direction[1], z = g.direction[2];
+    const float len = std::sqrt((x * x + y * y) + z * z);
+    const float rcp = 1.0f / len;
+    d.dir_n[0] = x * rcp;
+    d.dir_n[1] = y * rcp;
+    d.dir_n[2] = z * rcp;
+    return d;
+}
+
+int check_common(const rt_scene* scene, RtSettings st)
+{
+    if (!g_ctx.ready) return fail(RT_ERR_NOT_INIT, "rt_hip_init() has not been called");
+    if (!scene) return fail(RT_ERR_INVALID, "scene is null");
+    if (!(st.max_bounces < (1u << 20))) return fail(RT_ERR_INVALID, "max_bounces out of range");
+    return RT_OK;
+}
+
+int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream)
+{
+    unsigned idx = g_ctx.next_counter++ % kCounterRing;
+    p.next_cell = g_ctx.counters + idx;
+    p.total_segments = d_total;
+    HIP_TRY(hipMemsetAsync(p.next_cell, 0, sizeof(unsigned), stream));
+    if (d_total) HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(rt::launch_trace(p, g_ctx.n_cu, stream));
+    return RT_OK;
+}
+
+int g_scan_mode = 0;
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_hip_last_error(void) { return g_err.c_str(); }
+
+int rt_hip_init(int device_ordinal)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(RT_ERR_INVALID, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RT_ERR_UNSUPPORTED, std::string("librt_hip.so is built for gfx950 only, device is ") + prop.gcnArchName);
+    if (g_ctx.ready && g_ctx.device != device_ordinal) {
+        (void)hipFree(g_ctx.counters);
+        g_ctx = Context{};
+    }
+    if (!g_ctx.ready) {
+        HIP_TRY(hipMalloc((void**)&g_ctx.counters, kCounterRing * sizeof(unsigned)));
+        g_ctx.device = device_ordinal;
+        g_ctx.n_cu = prop.multiProcessorCount;
+        g_ctx.ready = true;
+    }
+    return RT_OK;
+}
+
+void rt_hip_shutdown(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_ctx.ready) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(g_ctx.counters);
+        g_ctx = Context{};
+    }
+}
+
+int rt_hip_set_scan_mode(int mode)
+{
+    if (mode != 0 && mode != 1) return fail(RT_ERR_INVALID, "scan mode must be 0 or 1");
+    g_scan_mode = mode;
+    return RT_OK;
+}
+
+int rt_hip_scene_create(const RtObject* objects, uint64_t n_objects, rt_scene** out_scene)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_ctx.ready) return fail(RT_ERR_NOT_INIT, "rt_hip_init() has not been called");
+    if (!out_scene || (!objects && n_objects)) return fail(RT_ERR_INVALID, "null argument");
+    if (n_objects >= (1ull << 23)) return fail(RT_ERR_INVALID, "too many objects (limit 2^23)");
+    *out_scene = nullptr;
+
+    std::vector<float4> sph_cull, sph_exact, pl_pos, pl_nrm, obj_geom(n_objects), obj_aux(n_objects);
+    std::vector<int32_t> sph_obj, pl_obj;
+    std::vector<uint2> obj_mat(n_objects);
+    std::vector<uint32_t> obj_shape(n_objects);
+    double c2max = 0.0;
+    for (uint64_t k = 0; k < n_objects; ++k) {
+        const RtObject& o = objects[k];
+        if (o.material_kind > RT_MAT_HALF_MIRROR) return fail(RT_ERR_INVALID, "object " + std::to_string(k) + ": unknown material kind");
+        if (o.rotation_y_deg != 0.0f)
+            return fail(RT_ERR_UNSUPPORTED, "object " + std::to_string(k) + ": rotation_y_deg != 0 is not on the GPU path yet");
+        uint32_t pbits;
+        std::memcpy(&pbits, &o.material_param, 4);
+        obj_mat[k] = make_uint2(o.material_kind, pbits);
+        obj_shape[k] = o.shape;
+        const float px = o.position[0], py = o.position[1], pz = o.position[2];
+        if (o.shape == RT_SHAPE_SPHERE) {
+            const float r = o.shape_param[0];
+            const double pp = (double)px * px + (double)py * py + (double)pz * pz;
+            const double rr = (double)r * r;
+            sph_cull.push_back(make_float4(px, py, pz, (float)(pp - rr)));
+            sph_exact.push_back(make_float4(px, py, pz, r));
+            sph_obj.push_back((int32_t)k);
+            obj_geom[k] = make_float4(px, py, pz, r);
+            obj_aux[k] = make_float4(0, 0, 0, 0);
+            if (pp + rr > c2max) c2max = pp + rr;
+        } else if (o.shape == RT_SHAPE_PLANE) {
+            pl_pos.push_back(make_float4(px, py, pz, 0));
+            pl_nrm.push_back(make_float4(o.shape_param[0], o.shape_param[1], o.shape_param[2], 0));
+            pl_obj.push_back((int32_t)k);
+            obj_geom[k] = make_float4(px, py, pz, 0);
+            obj_aux[k] = make_float4(o.shape_param[0], o.shape_param[1], o.shape_param[2], 0);
+        } else {
+            return fail(RT_ERR_UNSUPPORTED, "object " + std::to_string(k) + ": shape is not on the GPU path yet (Sphere and Plane are)");
+        }
+    }
+    const uint32_t n_sph = (uint32_t)sph_cull.size();
+    const uint32_t n_pad = (n_sph + rt::kUnroll - 1) / rt::kUnroll * rt::kUnroll;
+    const float inf = std::numeric_limits<float>::infinity();
+    for (uint32_t k = n_sph; k < n_pad; ++k) {
+        sph_cull.push_back(make_float4(0, 0, 0, inf));  // never passes the filter
+        sph_exact.push_back(make_float4(0, 0, 0, 1));
+        sph_obj.push_back(-1);
+    }
+    float c2max_f = (float)c2max;
+    if ((double)c2max_f < c2max) c2max_f = std::nextafter(c2max_f, inf);
+
+    rt_scene* s = new rt_scene;
+    rt::DevScene& d = s->dev;
+    hipError_t e = hipSuccess;
+    auto up = [&](auto& vec, auto** dst) {
+        if (e != hipSuccess) return;
+        e = upload(vec, dst);
+        if (e == hipSuccess) s->allocations.push_back((void*)*dst);
+    };
+    up(sph_cull, &d.sph_cull);
+    up(sph_exact, &d.sph_exact);
+    up(sph_obj, &d.sph_obj);
+    up(pl_pos, &d.pl_pos);
+    up(pl_nrm, &d.pl_nrm);
+    up(pl_obj, &d.pl_obj);
+    up(obj_geom, &d.obj_geom);
+    up(obj_aux, &d.obj_aux);
+    up(obj_mat, &d.obj_mat);
+    up(obj_shape, &d.obj_shape);
+    if (e != hipSuccess) {
+        free_scene(s);
+        return fail_hip(e, "scene upload");
+    }
+    d.n_sph = n_sph;
+    d.n_sph_pad = n_pad;
+    d.n_pl = (uint32_t)pl_pos.size();
+    d.n_obj = (uint32_t)n_objects;
+    d.c2max = c2max_f;
+    *out_scene = s;
+    return RT_OK;
+}
+
+void rt_hip_scene_destroy(rt_scene* scene)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    free_scene(scene);
+}
+
+int rt_hip_scene_counts(const rt_scene* scene, uint64_t* n_objects, uint64_t* n_spheres, uint64_t* n_planes)
+{
+    if (!scene) return fail(RT_ERR_INVALID, "scene is null");
+    if (n_objects) *n_objects = scene->dev.n_obj;
+    if (n_spheres) *n_spheres = scene->dev.n_sph;
+    if (n_planes) *n_planes = scene->dev.n_pl;
+    return RT_OK;
+}
+
+int rt_hip_simulate_dev(const rt_scene* scene, const RtRay* d_rays, uint64_t n_rays, RtSettings settings, uint64_t seed,
+                        uint64_t ray_id_base, float* d_points, uint32_t* d_n_points, RtBounceRecord* d_records,
+                        uint64_t* d_total_segments, void* stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = check_common(scene, settings)) return rc;
+    if (n_rays == 0) return RT_OK;
+    if (!d_rays || !d_points || !d_n_points) return fail(RT_ERR_INVALID, "rays / points / n_points must not be null");
+    if (n_rays > 0x7fffffffull) return fail(RT_ERR_INVALID, "n_rays exceeds 2^31-1 per call");
+    if (settings.max_bounces == 0) return fail(RT_ERR_INVALID, "max_bounces == 0 is handled by the host entry point only");
+    rt::TraceParams p{};
+    p.sc = scene->dev;
+    p.rays = d_rays;
+    p.spp = 1;
+    p.cell_count = (uint32_t)n_rays;
+    p.cell_begin = 0;
+    p.cell_step = 1;
+    p.path_id_base = ray_id_base;
+    p.st = settings;
+    p.seed = seed;
+    p.points = d_points;
+    p.n_points = d_n_points;
+    p.records = d_records;
+    p.scan_mode = g_scan_mode;
+    return enqueue(p, (unsigned long long*)d_total_segments, (hipStream_t)stream);
+}
+
+int rt_hip_simulate(const rt_scene* scene, const RtRay* rays, uint64_t n_rays, RtSettings settings, uint64_t seed,
+                    uint64_t ray_id_base, float* out_points, uint32_t* out_n_points, RtBounceRecord* out_records)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (int rc = check_common(scene, settings)) return rc;
+    }
+    if (n_rays == 0) return RT_OK;
+    if (!rays || !out_points || !out_n_points) return fail(RT_ERR_INVALID, "rays / out_points / out_n_points must not be null");
+    if (settings.max_bounces == 0) {  // scene.rs:45-49: the path is just its origin
+        for (uint64_t r = 0; r < n_rays; ++r) {
+            std::memcpy(out_points + r * 3, rays[r].origin, 12);
+            out_n_points[r] = 1;
+        }
+        return RT_OK;
+    }
+    const size_t pts_bytes = sizeof(float) * 3 * ((size_t)settings.max_bounces + 1) * n_rays;
+    const size_t rec_bytes = sizeof(RtBounceRecord) * (size_t)settings.max_bounces * n_rays;
+    RtRay* d_rays = nullptr;
+    float* d_pts = nullptr;
+    uint32_t* d_np = nullptr;
+    RtBounceRecord* d_rec = nullptr;
+    int rc = RT_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(d_rays);
+        (void)hipFree(d_pts);
+        (void)hipFree(d_np);
+        (void)hipFree(d_rec);
+    };
+#define TRY_OR_CLEAN(expr)                       \
+    do {                                         \
+        hipError_t e_ = (expr);                  \
+        if (e_ != hipSuccess) {                  \
+            cleanup();                           \
+            return fail_hip(e_, #expr);          \
+        }                                        \
+    } while (0)
+    TRY_OR_CLEAN(hipMalloc((void**)&d_rays, sizeof(RtRay) * n_rays));
+    TRY_OR_CLEAN(hipMalloc((void**)&d_pts, pts_bytes));
+    TRY_OR_CLEAN(hipMalloc((void**)&d_np, sizeof(uint32_t) * n_rays));
+    if (out_records) TRY_OR_CLEAN(hipMalloc((void**)&d_rec, rec_bytes));
+    TRY_OR_CLEAN(hipMemcpy(d_rays, rays, sizeof(RtRay) * n_rays, hipMemcpyHostToDevice));
+    TRY_OR_CLEAN(hipMemset(d_pts, 0, pts_bytes));
+    if (d_rec) TRY_OR_CLEAN(hipMemset(d_rec, 0, rec_bytes));
+    rc = rt_hip_simulate_dev(scene, d_rays, n_rays, settings, seed, ray_id_base, d_pts, d_np, d_rec, nullptr, nullptr);
+    if (rc != RT_OK) {
+        cleanup();
+        return rc;
+    }
+    TRY_OR_CLEAN(hipDeviceSynchronize());
+    TRY_OR_CLEAN(hipMemcpy(out_points, d_pts, pts_bytes, hipMemcpyDeviceToHost));
+    TRY_OR_CLEAN(hipMemcpy(out_n_points, d_np, sizeof(uint32_t) * n_rays, hipMemcpyDeviceToHost));
+    if (d_rec) TRY_OR_CLEAN(hipMemcpy(out_records, d_rec, rec_bytes, hipMemcpyDeviceToHost));
+    cleanup();
+    return RT_OK;
+}
+
+int rt_hip_render_dev(const rt_scene* scene, const RtRayGenerator* gen, uint32_t spp, RtSettings settings, uint64_t seed,
+                      uint64_t cell_begin, uint64_t cell_count, uint64_t cell_step, float* d_fb, int32_t* d_first_id,
+                      float* d_first_t, uint32_t* d_seg_count, uint64_t* d_total_segments, void* stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = check_common(scene, settings)) return rc;
+    if (!gen || !d_fb) return fail(RT_ERR_INVALID, "gen / fb must not be null");
+    if (gen->kind > RT_GEN_PROJECTOR) return fail(RT_ERR_INVALID, "unknown generator kind");
+    if (gen->count_u == 0 || gen->count_v == 0 || spp == 0) return fail(RT_ERR_INVALID, "count_u, count_v and spp must be > 0");
+    if (cell_count == 0) return RT_OK;
+    if (cell_count > 0x7fffffffull) return fail(RT_ERR_INVALID, "cell_count exceeds 2^31-1 per call");
+    if (cell_step == 0) return fail(RT_ERR_INVALID, "cell_step must be > 0");
+    const uint64_t n_cells = (uint64_t)gen->count_u * gen->count_v;
+    if (cell_begin + (cell_count - 1) * cell_step >= n_cells) return fail(RT_ERR_INVALID, "cell range exceeds count_u*count_v");
+    if (settings.max_bounces == 0) return fail(RT_ERR_INVALID, "max_bounces == 0 is handled by the host entry point only");
+    rt::TraceParams p{};
+    p.sc = scene->dev;
+    p.rays = nullptr;
+    p.gen = make_dev_gen(*gen);
+    p.spp = spp;
+    p.cell_count = (uint32_t)cell_count;
+    p.cell_begin = cell_begin;
+    p.cell_step = cell_step;
+    p.st = settings;
+    p.seed = seed;
+    p.fb = d_fb;
+    p.first_id = d_first_id;
+    p.first_t = d_first_t;
+    p.seg_count = d_seg_count;
+    p.scan_mode = g_scan_mode;
+    return enqueue(p, (unsigned long long*)d_total_segments, (hipStream_t)stream);
+}
+
+int rt_hip_render(const rt_scene* scene, const RtRayGenerator* gen, uint32_t spp, RtSettings settings, uint64_t seed,
+                  uint64_t cell_begin, uint64_t cell_count, uint64_t cell_step, float* out_fb, int32_t* out_first_id,
+                  float* out_first_t, uint32_t* out_seg_count, uint64_t* out_total_segments)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (int rc = check_common(scene, settings)) return rc;
+    }
+    if (!gen || !out_fb) return fail(RT_ERR_INVALID, "gen / out_fb must not be null");
+    if (cell_count == 0) {
+        if (out_total_segments) *out_total_segments = 0;
+        return RT_OK;
+    }
+    if (settings.max_bounces == 0) {  // no segment is ever traced: every path value is 0
+        std::memset(out_fb, 0, sizeof(float) * 3 * cell_count);
+        for (uint64_t m = 0; m < cell_count; ++m) {
+            if (out_first_id) out_first_id[m] = -1;
+            if (out_first_t) out_first_t[m] = std::numeric_limits<float>::infinity();
+            if (out_seg_count) out_seg_count[m] = 0;
+        }
+        if (out_total_segments) *out_total_segments = 0;
+        return RT_OK;
+    }
+    float* d_fb = nullptr;
+    int32_t* d_id = nullptr;
+    float* d_t = nullptr;
+    uint32_t* d_seg = nullptr;
+    uint64_t* d_tot = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_fb);
+        (void)hipFree(d_id);
+        (void)hipFree(d_t);
+        (void)hipFree(d_seg);
+        (void)hipFree(d_tot);
+    };
+    TRY_OR_CLEAN(hipMalloc((void**)&d_fb, sizeof(float) * 3 * cell_count));
+    if (out_first_id) TRY_OR_CLEAN(hipMalloc((void**)&d_id, sizeof(int32_t) * cell_count));
+    if (out_first_t) TRY_OR_CLEAN(hipMalloc((void**)&d_t, sizeof(float) * cell_count));
+    if (out_seg_count) TRY_OR_CLEAN(hipMalloc((void**)&d_seg, sizeof(uint32_t) * cell_count));
+    TRY_OR_CLEAN(hipMalloc((void**)&d_tot, sizeof(uint64_t)));
+    int rc = rt_hip_render_dev(scene, gen, spp, settings, seed, cell_begin, cell_count, cell_step, d_fb, d_id, d_t, d_seg, d_tot, nullptr);
+    if (rc != RT_OK) {
+        cleanup();
+        return rc;
+    }
+    TRY_OR_CLEAN(hipDeviceSynchronize());
+    TRY_OR_CLEAN(hipMemcpy(out_fb, d_fb, sizeof(float) * 3 * cell_count, hipMemcpyDeviceToHost));
+    if (d_id) TRY_OR_CLEAN(hipMemcpy(out_first_id, d_id, sizeof(int32_t) * cell_count, hipMemcpyDeviceToHost));
+    if (d_t) TRY_OR_CLEAN(hipMemcpy(out_first_t, d_t, sizeof(float) * cell_count, hipMemcpyDeviceToHost));
+    if (d_seg) TRY_OR_CLEAN(hipMemcpy(out_seg_count, d_seg, sizeof(uint32_t) * cell_count, hipMemcpyDeviceToHost));
+    if (out_total_segments) TRY_OR_CLEAN(hipMemcpy(out_total_segments, d_tot, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    cleanup();
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// rt_internal.h — types shared by the C-ABI host code (rt_capi.cpp) and the gfx950 kernels (rt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_hip.h"
+
+namespace rt {
+
+constexpr int kTileSpheres = 2048;  // spheres per LDS tile (32 KiB of float4)
+constexpr int kBlockThreads = 256;  // 4 waves
+constexpr int kUnroll = 4;          // spheres per scan step; sphere arrays are padded to a multiple
+
+// Flattened scene as the kernels see it (all pointers are device memory).
+struct DevScene {
+    const float4* sph_cull;   // [n_sph_pad] {px, py, pz, K = |p|^2 - r^2}; padding has K = +inf
+    const float4* sph_exact;  // [n_sph_pad] {px, py, pz, r}
+    const int32_t* sph_obj;   // [n_sph_pad] object-list index of sphere j (increasing in j)
+    const float4* pl_pos;     // [n_pl] {px, py, pz, 0}
+    const float4* pl_nrm;     // [n_pl] {nx, ny, nz, 0} (not normalised, as configured)
+    const int32_t* pl_obj;    // [n_pl]
+    const float4* obj_geom;   // [n_obj] sphere: {px,py,pz,r}; plane: {px,py,pz,0}
+    const float4* obj_aux;    // [n_obj] plane: {nx,ny,nz,0}
+    const uint2* obj_mat;     // [n_obj] {material kind, bits of material param}
+    const uint32_t* obj_shape;  // [n_obj]
+    uint32_t n_sph, n_sph_pad, n_pl, n_obj;
+    float c2max;  // >= max_j (|p_j|^2 + r_j^2), rounded up: magnitude bound used by the cull margin
+};
+
+// Host-precomputed generator constants (scene_config.rs:70-72, 96-97): the per-component divisions and the
+// ParallelGrid normalisation are done once on the host with the same IEEE operations.
+struct DevGen {
+    uint32_t kind, count_u, count_v;
+    float current_ior;
+    float a[3], corner[3], u_step[3], v_step[3], dir_n[3];
+};
+
+struct TraceParams {
+    DevScene sc;
+    const RtRay* rays;  // explicit rays (simulate) or nullptr (generator mode)
+    DevGen gen;
+    uint32_t spp;
+    uint32_t cell_count;  // number of work items m (cells or rays), < 2^32
+    uint64_t cell_begin, cell_step;
+    uint64_t path_id_base;
+    RtSettings st;
+    uint64_t seed;
+    float* fb;
+    int32_t* first_id;
+    float* first_t;
+    uint32_t* seg_count;
+    float* points;
+    uint32_t* n_points;
+    RtBounceRecord* records;
+    unsigned long long* total_segments;  // accumulated with atomics; zeroed by the launcher
+    unsigned int* next_cell;             // work counter; zeroed by the launcher
+    int scan_mode;                       // 0 = conservative cull, 1 = exact discriminant filter
+};
+
+// Launches the trace kernel on `stream`; d_work = {unsigned long long total_segments; unsigned next_cell} scratch.
+hipError_t launch_trace(const TraceParams& p, int n_cu, hipStream_t stream);
+
+}  // namespace rt
