@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the ray-path hot loop on the C2 workload (BASELINE.json configs[1]).
+
+A step = one pass of the hot path over one frame of synthetic input: 1,000 spheres, Projector 1920x1080 cells,
+64 paths per cell, max_bounces 8.  A "ray" = one bounce-loop iteration (scene.rs:49), counted by
+the kernel.  N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders the same frame for
+its own sample block (weak scaling) and the framebuffers are summed to rank 0 over RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_TEST = 17  # algorithmic reject-path cost of one ray-sphere test (sphere.rs:13-17)
+PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (packed FMA)
+
+
+def cpu_baseline(cfg, n_spheres):
+    """Oracle (C++ restatement, kind 'port') on the host cores, on a bounded sample of the same workload."""
+    from oracle import binding as ob
+    from raytracing_amd import synth
+
+    small = synth.config_c2(192, 108)
+    osc = ob.OracleScene(small["objects"])
+    spp = 8
+    t0 = time.perf_counter()
+    *_, total = osc.render(small["gen"], spp, small["infinity_distance"], small["max_bounces"], seed=small["seed"], threads=1)
+    dt1 = time.perf_counter() - t0
+    threads = min(16, os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    *_, total_mt = osc.render(small["gen"], spp * 4, small["infinity_distance"], small["max_bounces"], seed=small["seed"], threads=threads)
+    dtn = time.perf_counter() - t0
+    return {
+        "value": total / dt1 / 1e6,
+        "unit": "Mrays/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"C2 scene ({n_spheres} spheres), 192x108 cells x {spp} spp, depth 8: {total} segments in {dt1:.2f} s, 1 thread "
+                  "(C++ restatement of the reference; the Rust binary cannot be built here)",
+        "all_cores": {"value": total_mt / dtn / 1e6, "cores": threads, "sample": f"192x108 x {spp * 4} spp, {total_mt} segments in {dtn:.2f} s"},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from raytracing_amd import engine, synth
+    from raytracing_amd.engine import SimulationSettingsConfig
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    engine.init(dev.index)
+
+    cfg = synth.config_c2(args.width, args.height)
+    cfg["spp"] = args.spp
+    scene = engine.Scene(cfg["objects"])
+    n_obj, n_sph, n_pl = scene.counts()
+    st = SimulationSettingsConfig(cfg["infinity_distance"], cfg["max_bounces"])
+    n_cells = args.width * args.height
+    # inputs (scene, generator constants) and outputs resident in HBM before the timed region
+    fb = torch.empty((n_cells, 3), dtype=torch.float32, device=dev)
+    first_id = torch.empty(n_cells, dtype=torch.int32, device=dev)
+    first_t = torch.empty(n_cells, dtype=torch.float32, device=dev)
+    seg = torch.empty(n_cells, dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    seed = (cfg["seed"] + rank * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF  # rank = sample block
+
+    def step():
+        stream = torch.cuda.current_stream().cuda_stream
+        scene.render_dev(cfg["gen"], cfg["spp"], st, seed, 0, n_cells, 1, fb.data_ptr(), first_id.data_ptr(), first_t.data_ptr(),
+                         seg.data_ptr(), total.data_ptr(), stream)
+        if world > 1:
+            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # kernel duration: HIP events on the launch stream around each render_dev (no collective inside the pair)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    segs_done = 0
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        stream = torch.cuda.current_stream().cuda_stream
+        scene.render_dev(cfg["gen"], cfg["spp"], st, seed, 0, n_cells, 1, fb.data_ptr(), first_id.data_ptr(), first_t.data_ptr(),
+                         seg.data_ptr(), total.data_ptr(), stream)
+        ev[k][1].record()
+        if world > 1:
+            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    segs_per_step = int(total.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    s = torch.tensor([segs_per_step], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    elapsed_max = float(t.item())
+    segs_all = int(s.item())
+
+    if rank == 0:
+        value = segs_all * args.steps / elapsed_max / 1e6
+        achieved = segs_per_step * FLOP_PER_TEST * n_sph / (kernel_ms * 1e-3) / 1e12
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/sec (primary+bounce) at 1080p 64spp",
+            "value": value,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2: {n_sph} spheres (seed 0xC0FFEE), Projector {args.width}x{args.height} cells, {cfg['spp']} spp, "
+                            f"max_bounces {cfg['max_bounces']}; one frame per GPU per step",
+                "segments_per_step_per_gpu": segs_per_step,
+                "sharding": "one sample block (frame) per rank; framebuffer reduce to rank 0 over RCCL" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "valu_fp32",
+                "kernel": "trace_kernel",
+                "achieved": achieved,
+                "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_TFLOPS,
+                "traffic": traffic,
+                "kernel_ms": kernel_ms,
+                "flop_per_segment": FLOP_PER_TEST * n_sph,
+                "note": "algorithmic 17 FLOP per ray-sphere test x spheres x segments / kernel time (HIP events on the launch stream)",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, n_sph)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
