@@ -448,7 +448,7 @@ static void render_range(const orc_scene* s, const RtRayGenerator* gen, uint32_t
     for (uint64_t m = m0; m < m1; ++m) {
         uint64_t cell = cell_begin + m * cell_step;
         Ray ray = generate_ray(*gen, cell);
-        V3 acc = v3(0, 0, 0);
+        uint64_t accx = 0, accy = 0, accz = 0;  // fixed-point 2^-24 sums (order-independent)
         uint32_t segs = 0;
         for (uint32_t sidx = 0; sidx < spp; ++sidx) {
             bool esc;
@@ -461,12 +461,14 @@ static void render_range(const orc_scene* s, const RtRayGenerator* gen, uint32_t
                 if (first_t) first_t[m] = st.max_bounces ? recs[0].t : std::numeric_limits<float>::infinity();
             }
             V3 val = esc ? sky(fd) : v3(0, 0, 0);
-            acc = acc + val;
+            accx += (uint64_t)std::llrintf(val.x * 16777216.0f);
+            accy += (uint64_t)std::llrintf(val.y * 16777216.0f);
+            accz += (uint64_t)std::llrintf(val.z * 16777216.0f);
         }
-        float fs = (float)spp;
-        fb[m * 3 + 0] = acc.x / fs;
-        fb[m * 3 + 1] = acc.y / fs;
-        fb[m * 3 + 2] = acc.z / fs;
+        const double denom = (double)spp * 16777216.0;
+        fb[m * 3 + 0] = (float)((double)accx / denom);
+        fb[m * 3 + 1] = (float)((double)accy / denom);
+        fb[m * 3 + 2] = (float)((double)accz / denom);
         if (seg_count) seg_count[m] = segs;
         tot += segs;
     }

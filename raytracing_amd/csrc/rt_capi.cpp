@@ -21,8 +21,10 @@ struct Context {
     bool ready = false;
     int device = -1;
     int n_cu = 0;
-    unsigned int* counters = nullptr;  // ring of per-launch work counters
+    unsigned long long* counters = nullptr;  // ring of per-launch work counters
     unsigned next_counter = 0;
+    unsigned long long* fb_q = nullptr;  // fixed-point framebuffer scratch (grow-only)
+    size_t fb_q_bytes = 0;
 };
 Context g_ctx;
 constexpr unsigned kCounterRing = 1024;
@@ -113,9 +115,9 @@ int check_common(const rt_scene* scene, RtSettings st)
 int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream)
 {
     unsigned idx = g_ctx.next_counter++ % kCounterRing;
-    p.next_cell = g_ctx.counters + idx;
+    p.next_unit = g_ctx.counters + idx;
     p.total_segments = d_total;
-    HIP_TRY(hipMemsetAsync(p.next_cell, 0, sizeof(unsigned), stream));
+    HIP_TRY(hipMemsetAsync(p.next_unit, 0, sizeof(unsigned long long), stream));
     if (d_total) HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), stream));
     HIP_TRY(rt::launch_trace(p, g_ctx.n_cu, stream));
     return RT_OK;
@@ -142,10 +144,11 @@ int rt_hip_init(int device_ordinal)
         return fail(RT_ERR_UNSUPPORTED, std::string("librt_hip.so is built for gfx950 only, device is ") + prop.gcnArchName);
     if (g_ctx.ready && g_ctx.device != device_ordinal) {
         (void)hipFree(g_ctx.counters);
+        (void)hipFree(g_ctx.fb_q);
         g_ctx = Context{};
     }
     if (!g_ctx.ready) {
-        HIP_TRY(hipMalloc((void**)&g_ctx.counters, kCounterRing * sizeof(unsigned)));
+        HIP_TRY(hipMalloc((void**)&g_ctx.counters, kCounterRing * sizeof(unsigned long long)));
         g_ctx.device = device_ordinal;
         g_ctx.n_cu = prop.multiProcessorCount;
         g_ctx.ready = true;
@@ -159,6 +162,7 @@ void rt_hip_shutdown(void)
     if (g_ctx.ready) {
         (void)hipDeviceSynchronize();
         (void)hipFree(g_ctx.counters);
+        (void)hipFree(g_ctx.fb_q);
         g_ctx = Context{};
     }
 }
@@ -284,6 +288,8 @@ int rt_hip_simulate_dev(const rt_scene* scene, const RtRay* d_rays, uint64_t n_r
     p.sc = scene->dev;
     p.rays = d_rays;
     p.spp = 1;
+    p.unit_samples = 1;
+    p.units_per_cell = 1;
     p.cell_count = (uint32_t)n_rays;
     p.cell_begin = 0;
     p.cell_step = 1;
@@ -374,17 +380,34 @@ int rt_hip_render_dev(const rt_scene* scene, const RtRayGenerator* gen, uint32_t
     p.rays = nullptr;
     p.gen = make_dev_gen(*gen);
     p.spp = spp;
+    p.unit_samples = rt::kUnitSamples;
+    p.units_per_cell = (spp + rt::kUnitSamples - 1) / rt::kUnitSamples;
     p.cell_count = (uint32_t)cell_count;
     p.cell_begin = cell_begin;
     p.cell_step = cell_step;
     p.st = settings;
     p.seed = seed;
-    p.fb = d_fb;
+    // fixed-point accumulation scratch (grow-only; calls on a context are serialised, see rt_hip.h)
+    const size_t need = sizeof(unsigned long long) * 3 * cell_count;
+    if (need > g_ctx.fb_q_bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(g_ctx.fb_q);
+        g_ctx.fb_q = nullptr;
+        g_ctx.fb_q_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&g_ctx.fb_q, need));
+        g_ctx.fb_q_bytes = need;
+    }
+    hipStream_t hs = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(g_ctx.fb_q, 0, need, hs));
+    if (d_seg_count) HIP_TRY(hipMemsetAsync(d_seg_count, 0, sizeof(uint32_t) * cell_count, hs));
+    p.fb_q = g_ctx.fb_q;
     p.first_id = d_first_id;
     p.first_t = d_first_t;
     p.seg_count = d_seg_count;
     p.scan_mode = g_scan_mode;
-    return enqueue(p, (unsigned long long*)d_total_segments, (hipStream_t)stream);
+    if (int rc = enqueue(p, (unsigned long long*)d_total_segments, hs)) return rc;
+    HIP_TRY(rt::launch_finalize(g_ctx.fb_q, d_fb, (uint64_t)cell_count * 3, spp, hs));
+    return RT_OK;
 }
 
 int rt_hip_render(const rt_scene* scene, const RtRayGenerator* gen, uint32_t spp, RtSettings settings, uint64_t seed,

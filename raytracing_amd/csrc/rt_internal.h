@@ -7,8 +7,9 @@
 
 namespace rt {
 
-constexpr int kTileSpheres = 2048;  // spheres per LDS tile (32 KiB of float4)
+constexpr int kTileSpheres = 1024;  // spheres per LDS tile (16 KiB of float4): 4 blocks (16 waves) per CU
 constexpr int kBlockThreads = 256;  // 4 waves
+constexpr uint32_t kUnitSamples = 8;  // samples of one cell traced back to back by one lane (render work unit)
 constexpr int kUnroll = 4;          // spheres per scan step; sphere arrays are padded to a multiple
 
 // Flattened scene as the kernels see it (all pointers are device memory).
@@ -40,12 +41,14 @@ struct TraceParams {
     const RtRay* rays;  // explicit rays (simulate) or nullptr (generator mode)
     DevGen gen;
     uint32_t spp;
+    uint32_t unit_samples;    // samples per work unit (render); 1 for simulate
+    uint32_t units_per_cell;  // ceil(spp / unit_samples)
     uint32_t cell_count;  // number of work items m (cells or rays), < 2^32
     uint64_t cell_begin, cell_step;
     uint64_t path_id_base;
     RtSettings st;
     uint64_t seed;
-    float* fb;
+    unsigned long long* fb_q;  // [cell_count*3] fixed-point sums (2^-24), zeroed by the launcher
     int32_t* first_id;
     float* first_t;
     uint32_t* seg_count;
@@ -53,11 +56,12 @@ struct TraceParams {
     uint32_t* n_points;
     RtBounceRecord* records;
     unsigned long long* total_segments;  // accumulated with atomics; zeroed by the launcher
-    unsigned int* next_cell;             // work counter; zeroed by the launcher
+    unsigned long long* next_unit;       // work counter; zeroed by the launcher
     int scan_mode;                       // 0 = conservative cull, 1 = exact discriminant filter
 };
 
 // Launches the trace kernel on `stream`; d_work = {unsigned long long total_segments; unsigned next_cell} scratch.
 hipError_t launch_trace(const TraceParams& p, int n_cu, hipStream_t stream);
+hipError_t launch_finalize(const unsigned long long* fb_q, float* fb, uint64_t n_values, uint32_t spp, hipStream_t stream);
 
 }  // namespace rt

@@ -23,6 +23,8 @@
 // error bound derived in DESIGN.md ("Conservative filter").
 #include "rt_internal.h"
 
+#include <cstdlib>
+
 namespace rt {
 
 namespace {
@@ -165,9 +167,10 @@ __device__ __forceinline__ void push_candidates(WaveLds<R>& w, const DevScene& s
 struct Slot {
     F3 o, d;
     float ior;
-    F3 acc;
-    uint32_t m;       // work item
-    uint32_t sample;  // current sample index
+    unsigned long long accx, accy, accz;  // fixed-point (2^-24) sums of the unit's path values
+    uint32_t m;           // work item (cell / ray)
+    uint32_t sample;      // current sample index
+    uint32_t sample_end;  // one past the unit's last sample
     uint32_t bounce;
     uint32_t segs;    // segments of the current cell
     uint32_t np;      // polyline vertices written
@@ -208,7 +211,7 @@ __device__ __forceinline__ F3 sky(F3 d)
     return f3(k + w * 0.5f, k + w * 0.7f, k + w);
 }
 
-template <int R>
+template <int R, int MODE>
 __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams p)
 {
     __shared__ float4 tile[kTileSpheres];
@@ -235,13 +238,15 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
         s[r].bounce = 0;
         s[r].segs = 0;
         s[r].np = 0;
-        s[r].acc = f3(0, 0, 0);
+        s[r].accx = s[r].accy = s[r].accz = 0;
+        s[r].sample_end = 0;
         s[r].o = f3(0, 0, 0);
         s[r].d = f3(0, 0, 0);
         s[r].ior = 1.0f;
     }
     unsigned long long my_segments = 0;
-    bool exhausted = false;  // work counter ran past cell_count (wave-uniform)
+    bool exhausted = false;  // work counter ran past the last unit (wave-uniform)
+    const unsigned long long total_units = (unsigned long long)p.cell_count * p.units_per_cell;
     bool wave_done = false;
     const uint32_t max_b = p.st.max_bounces;
     const uint64_t stride_pts = (uint64_t)max_b + 1;
@@ -252,21 +257,32 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             bool any_live = false;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                bool need_cell = !s[r].live && (s[r].m == 0xffffffffu);
-                unsigned long long need = __ballot(need_cell);
+                bool need_unit = !s[r].live && (s[r].m == 0xffffffffu);
+                unsigned long long need = __ballot(need_unit);
                 if (need && !exhausted) {
                     unsigned cnt = (unsigned)__builtin_popcountll(need);
-                    unsigned base = 0;
-                    if (lane == 0) base = atomicAdd(p.next_cell, cnt);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base + cnt >= p.cell_count || base + cnt < base) exhausted = true;
-                    if (need_cell) {
-                        unsigned m = base + mbcnt64(need);
-                        if (m < p.cell_count && m >= base) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(p.next_unit, (unsigned long long)cnt);
+                    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
+                           __builtin_amdgcn_readfirstlane((unsigned)base);
+                    if (base + cnt >= total_units) exhausted = true;
+                    if (need_unit) {
+                        unsigned long long unit = base + mbcnt64(need);
+                        if (unit < total_units) {
+                            uint32_t m, k;
+                            if (p.units_per_cell == 1) {
+                                m = (uint32_t)unit;
+                                k = 0;
+                            } else {
+                                m = (uint32_t)(unit / p.units_per_cell);
+                                k = (uint32_t)(unit - (unsigned long long)m * p.units_per_cell);
+                            }
                             s[r].m = m;
-                            s[r].sample = 0;
+                            s[r].sample = k * p.unit_samples;
+                            uint32_t e = s[r].sample + p.unit_samples;
+                            s[r].sample_end = e < p.spp ? e : p.spp;
                             s[r].segs = 0;
-                            s[r].acc = f3(0, 0, 0);
+                            s[r].accx = s[r].accy = s[r].accz = 0;
                         }
                     }
                 }
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         bool pass;
-                        if (p.scan_mode == 0) {
+                        if (MODE == 0) {
                             float h = __builtin_fmaf(sp[u].x, dh[r].x, __builtin_fmaf(sp[u].y, dh[r].y, __builtin_fmaf(sp[u].z, dh[r].z, nod[r])));
                             float S = __builtin_fmaf(sp[u].x, pp[r].x, __builtin_fmaf(sp[u].y, pp[r].y, __builtin_fmaf(sp[u].z, pp[r].z, s0[r])));
                             float q = __builtin_fmaf(h, h, -S);
@@ -489,16 +505,21 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             }
             if (path_done) {
                 s[r].live = false;
-                s[r].acc = s[r].acc + value;
+                // fixed-point accumulation (DESIGN.md "path value"): order-independent, so units of one cell
+                // may finish in any order on any lane / GPU and the sum is still bit-identical
+                s[r].accx += (unsigned long long)__float2ll_rn(value.x * 16777216.0f);
+                s[r].accy += (unsigned long long)__float2ll_rn(value.y * 16777216.0f);
+                s[r].accz += (unsigned long long)__float2ll_rn(value.z * 16777216.0f);
                 if (p.n_points) p.n_points[s[r].m] = s[r].np;
                 ++s[r].sample;
-                if (s[r].sample == p.spp) {
-                    if (p.fb) {
-                        const float fs = (float)p.spp;
-                        float* f = p.fb + (uint64_t)s[r].m * 3;
-                        f[0] = s[r].acc.x / fs; f[1] = s[r].acc.y / fs; f[2] = s[r].acc.z / fs;
+                if (s[r].sample == s[r].sample_end) {
+                    if (p.fb_q) {
+                        unsigned long long* q = p.fb_q + (uint64_t)s[r].m * 3;
+                        if (s[r].accx) atomicAdd(q + 0, s[r].accx);
+                        if (s[r].accy) atomicAdd(q + 1, s[r].accy);
+                        if (s[r].accz) atomicAdd(q + 2, s[r].accz);
                     }
-                    if (p.seg_count) p.seg_count[s[r].m] = s[r].segs;
+                    if (p.seg_count) atomicAdd(p.seg_count + s[r].m, s[r].segs);
                     s[r].m = 0xffffffffu;
                 }
             }
@@ -516,16 +537,49 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
 
 }  // namespace
 
+// fb = sum_q / (spp * 2^24), IEEE f64 division rounded once to f32
+__global__ void finalize_kernel(const unsigned long long* __restrict__ q, float* __restrict__ fb, uint64_t n, double denom)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fb[i] = (float)((double)q[i] / denom);
+}
+
+template <class K>
+static int blocks_per_cu(K kernel)
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlockThreads, 0) != hipSuccess || n < 1) n = 1;
+    if (const char* e = getenv("RT_HIP_BLOCKS_PER_CU")) {  // tuning knob
+        int v = atoi(e);
+        if (v >= 1 && v <= 8) n = v;
+    }
+    return n;
+}
+
 hipError_t launch_trace(const TraceParams& p, int n_cu, hipStream_t stream)
 {
     constexpr int R = 2;
-    // persistent grid: enough blocks to fill every CU several waves deep, never more than the work needs
-    uint64_t slots_per_block = (uint64_t)kBlockThreads * R;
-    uint64_t want = ((uint64_t)p.cell_count + slots_per_block - 1) / slots_per_block;
-    uint64_t cap = (uint64_t)n_cu * 3;
+    static const int occ0 = blocks_per_cu(trace_kernel<R, 0>);
+    static const int occ1 = blocks_per_cu(trace_kernel<R, 1>);
+    // persistent grid: exactly the resident capacity (every block pulls cells until the counter runs out),
+    // never more blocks than the work can feed
+    const uint64_t slots_per_block = (uint64_t)kBlockThreads * R;
+    const uint64_t want = ((uint64_t)p.cell_count * p.units_per_cell + slots_per_block - 1) / slots_per_block;
+    const uint64_t cap = (uint64_t)n_cu * (p.scan_mode == 0 ? occ0 : occ1);
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(trace_kernel<R>, dim3(blocks), dim3(kBlockThreads), 0, stream, p);
+    if (p.scan_mode == 0)
+        hipLaunchKernelGGL((trace_kernel<R, 0>), dim3(blocks), dim3(kBlockThreads), 0, stream, p);
+    else
+        hipLaunchKernelGGL((trace_kernel<R, 1>), dim3(blocks), dim3(kBlockThreads), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const unsigned long long* fb_q, float* fb, uint64_t n_values, uint32_t spp, hipStream_t stream)
+{
+    const unsigned threads = 256;
+    const unsigned blocks = (unsigned)((n_values + threads - 1) / threads);
+    hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(threads), 0, stream, fb_q, fb, n_values, (double)spp * 16777216.0);
     return hipGetLastError();
 }
 
