@@ -29,13 +29,13 @@ def cpu_baseline(cfg, n_spheres):
 
     small = synth.config_c2(192, 108)
     osc = ob.OracleScene(small["objects"])
-    spp = 8
+    spp = 128  # ~10-15 s of single-thread work
     t0 = time.perf_counter()
     *_, total = osc.render(small["gen"], spp, small["infinity_distance"], small["max_bounces"], seed=small["seed"], threads=1)
     dt1 = time.perf_counter() - t0
     threads = min(16, os.cpu_count() or 1)
     t0 = time.perf_counter()
-    *_, total_mt = osc.render(small["gen"], spp * 4, small["infinity_distance"], small["max_bounces"], seed=small["seed"], threads=threads)
+    *_, total_mt = osc.render(small["gen"], spp * 2, small["infinity_distance"], small["max_bounces"], seed=small["seed"], threads=threads)
     dtn = time.perf_counter() - t0
     return {
         "value": total / dt1 / 1e6,
@@ -44,7 +44,7 @@ def cpu_baseline(cfg, n_spheres):
         "kind": "port",
         "sample": f"C2 scene ({n_spheres} spheres), 192x108 cells x {spp} spp, depth 8: {total} segments in {dt1:.2f} s, 1 thread "
                   "(C++ restatement of the reference; the Rust binary cannot be built here)",
-        "all_cores": {"value": total_mt / dtn / 1e6, "cores": threads, "sample": f"192x108 x {spp * 4} spp, {total_mt} segments in {dtn:.2f} s"},
+        "all_cores": {"value": total_mt / dtn / 1e6, "cores": threads, "sample": f"192x108 x {spp * 2} spp, {total_mt} segments in {dtn:.2f} s"},
     }
 
 

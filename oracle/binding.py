@@ -42,6 +42,8 @@ def lib():
         L.orc_uniform01.restype = C.c_float
         L.orc_uniform01.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
         L.orc_object_matrices.argtypes = [C.c_void_p, f3, f3]
+        u4 = C.POINTER(C.c_uint32)
+        L.orc_philox4x32_10.argtypes = [u4, u4, u4]
         _LIB = L
     return _LIB
 
@@ -133,6 +135,12 @@ def refract(i, n, ior_ratio):
 
 def uniform01(seed, path_id, bounce):
     return float(lib().orc_uniform01(seed, path_id, bounce))
+
+
+def philox4x32_10(ctr, key):
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+    return list(out)
 
 
 def object_matrices(obj):

@@ -251,10 +251,8 @@ inline bool refract(V3 incident, V3 normal, float ior_ratio, V3& out)
 // the seed, counter = (path id lo, path id hi, bounce, tag); rand 0.8 `Standard` f32 mapping
 // (next_u32() >> 8) * 2^-24.
 inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
-inline float uniform01(uint64_t seed, uint64_t path_id, uint32_t bounce)
+inline void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1)
 {
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    uint32_t c0 = (uint32_t)path_id, c1 = (uint32_t)(path_id >> 32), c2 = bounce, c3 = 0x52415953u;
     for (int r = 0; r < 10; ++r) {
         uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
@@ -263,6 +261,11 @@ inline float uniform01(uint64_t seed, uint64_t path_id, uint32_t bounce)
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
+}
+inline float uniform01(uint64_t seed, uint64_t path_id, uint32_t bounce)
+{
+    uint32_t c0 = (uint32_t)path_id, c1 = (uint32_t)(path_id >> 32), c2 = bounce, c3 = 0x52415953u;
+    philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
     return (float)(c0 >> 8) * (1.0f / 16777216.0f);
 }
 
@@ -549,6 +552,12 @@ int orc_refract(const float i[3], const float n[3], float ior_ratio, float out[3
     return 1;
 }
 float orc_uniform01(uint64_t seed, uint64_t path_id, uint32_t bounce) { return uniform01(seed, path_id, bounce); }
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    philox4x32_10(c0, c1, c2, c3, key[0], key[1]);
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
 // transform / inverse of T(position)*R_y(deg) as 16 column-major floats each (for the exactness test).
 void orc_object_matrices(const RtObject* o, float transform[16], float inverse_transform[16])
 {

@@ -1,0 +1,54 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/rt_hip.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from raytracing_amd import _lib, abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_hip_\w+)\s*\(", text)))
+
+
+def test_header_and_export_list_agree():
+    assert _declared() == sorted(_lib.EXPORTS)
+
+
+def test_library_loads_and_exports_every_symbol():
+    L = _lib.lib()
+    for name in _declared():
+        assert getattr(L, name) is not None
+
+
+def test_struct_layouts_match_header():
+    assert abi.OBJECT_DTYPE.itemsize == 44 and abi.RAY_DTYPE.itemsize == 28 and abi.RECORD_DTYPE.itemsize == 52
+    assert C.sizeof(abi.RtRayGenerator) == 76 and C.sizeof(abi.RtSettings) == 8
+    assert abi.RECORD_DTYPE.fields["dir_out"][1] == 36 and abi.OBJECT_DTYPE.fields["shape_param"][1] == 28
+
+
+def test_calls_without_init_fail_with_error_code():
+    """No GPU needed: the entry points must refuse to run before rt_hip_init (no silent fallback)."""
+    L = _lib.lib()
+    h = C.c_void_p()
+    objs = np.zeros(1, abi.OBJECT_DTYPE)
+    rc = L.rt_hip_scene_create(abi.ptr(objs), 1, C.byref(h))
+    assert rc == abi.RT_ERR_NOT_INIT
+    assert b"rt_hip_init" in L.rt_hip_last_error()
+    assert L.rt_hip_set_scan_mode(5) == abi.RT_ERR_INVALID
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under raytracing_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "raytracing_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "liboracle" not in text and not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f

@@ -157,3 +157,109 @@ def test_half_mirror_stream_is_counter_based(engine):
     assert_records_equal(full[2], want[2], "halfmirror")
     other = sc.simulate_rays_raw(st, rays=rays, seed=43)
     assert not np.array_equal(other[1], full[1]) or not np.array_equal(other[2]["obj_id"], full[2]["obj_id"])
+
+
+import os
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name,args,kw", [("c1_paths", (50.0, 10), {}), ("synth200_paths", (40.0, 8), dict(seed=5, ray_id_base=1000))])
+def test_gpu_matches_golden_paths(engine, name, args, kw):
+    """Committed fixtures (tests/golden/make_golden.py): the C1 scene of the reference's simulation.toml and a seeded scene."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    sc = engine.Scene(g["objects"])
+    pts, npts, recs = sc.simulate_rays_raw(SimulationSettingsConfig(*args), rays=g["rays"], **kw)
+    assert np.array_equal(npts, g["n_points"]) and np.array_equal(pts, g["points"])
+    assert_records_equal(recs, g["records"], name)
+
+
+def test_gpu_matches_golden_render(engine):
+    g = np.load(os.path.join(GOLD, "c2_48x27_4spp.npz"))
+    c2 = synth.config_c2(48, 27)
+    fb, fid, ft, seg, tot = engine.Scene(c2["objects"]).render(c2["gen"], 4, SimulationSettingsConfig(c2["infinity_distance"], c2["max_bounces"]),
+                                                               seed=c2["seed"])
+    assert np.array_equal(fb, g["fb"]) and np.array_equal(fid, g["first_id"]) and np.array_equal(ft, g["first_t"])
+    assert np.array_equal(seg, g["seg_count"]) and tot == int(g["total"])
+
+
+def test_c1_toml_end_to_end(engine):
+    """cli.rs:12-14 flow on the GPU: load TOML -> Scene -> simulate_rays -> polylines equal the oracle's."""
+    from raytracing_amd.config import SimulationConfig
+
+    cfg = SimulationConfig.load_from_path(os.path.join(GOLD, "c1_scene.toml"))
+    scene = cfg.scene.into_scene()
+    paths = scene.simulate_rays(cfg.simulation_settings)
+    g = np.load(os.path.join(GOLD, "c1_paths.npz"))
+    assert len(paths) == 3
+    for k, p in enumerate(paths):
+        assert np.array_equal(p, g["points"][k, : g["n_points"][k]])
+
+
+def test_full_size_c2_properties(engine):
+    """BASELINE.json configs[1] at full size (1920x1080, 64 spp): size-independent checks + sampled oracle comparison."""
+    c2 = synth.config_c2()
+    sc = engine.Scene(c2["objects"])
+    st = SimulationSettingsConfig(c2["infinity_distance"], c2["max_bounces"])
+    fb, fid, ft, seg, tot = sc.render(c2["gen"], c2["spp"], st, seed=c2["seed"])
+    n = 1920 * 1080
+    assert tot == int(seg.astype(np.int64).sum())  # checksum of checksums
+    assert seg.min() >= 64 and seg.max() <= 64 * 8  # every path has 1..max_bounces segments
+    assert np.all(seg[fid < 0] == 64)  # primary miss: exactly one segment per path
+    assert np.all(np.isinf(ft[fid < 0])) and np.all(ft[fid >= 0] > 0.001)
+    assert np.all((fb >= 0) & (fb <= 1.0))
+    # idempotence: a second run is bit-identical although lanes pick up work in a different order
+    fb2, fid2, ft2, seg2, tot2 = sc.render(c2["gen"], c2["spp"], st, seed=c2["seed"])
+    assert tot2 == tot and np.array_equal(fb2, fb) and np.array_equal(seg2, seg) and np.array_equal(fid2, fid)
+    # sampled cells against the oracle: first-hit id/t, segment count and pixel value bit-exact
+    rng = np.random.default_rng(0)
+    hit_cells = np.flatnonzero(fid >= 0)
+    cells = np.concatenate([rng.choice(n, 300, replace=False), rng.choice(hit_cells, 300, replace=False)])
+    osc = ob.OracleScene(c2["objects"])
+    for c in cells[:: max(1, len(cells) // 120)]:
+        ofb, ofid, oft, oseg, _ = osc.render(c2["gen"], c2["spp"], c2["infinity_distance"], c2["max_bounces"], seed=c2["seed"],
+                                            cell_begin=int(c), cell_count=1)
+        assert ofid[0] == fid[c] and oft[0] == ft[c] and oseg[0] == seg[c] and np.array_equal(ofb[0], fb[c]), int(c)
+    # sharding: two interleaved halves reassemble the same image
+    from raytracing_amd import sharding
+
+    parts = []
+    for rank in range(2):
+        b, cnt, step = sharding.cell_shard(rank, 2, n)
+        parts.append(sc.render(c2["gen"], c2["spp"], st, seed=c2["seed"], cell_begin=b, cell_count=cnt, cell_step=step)[0])
+    assert np.array_equal(sharding.interleave_shards(np.stack(parts), n), fb)
+
+
+def test_many_planes_and_far_hits(engine):
+    """Far plane hits give bounce origins with large |o|: the filter's margin grows with |o|^2 and must stay conservative."""
+    objs = list(random_scene(120, 0, seed=8))
+    objs += [plane((0, -900, 0), (0, 1, 0), abi.RT_MAT_MIRROR), plane((0, 900, 0), (0.05, -1, 0.02), abi.RT_MAT_MIRROR),
+             plane((4000, 0, 0), (-1, 0.01, 0), abi.RT_MAT_GLASS, 1.3)]
+    objs = np.array(objs, dtype=abi.OBJECT_DTYPE)
+    rays = random_rays(4000, seed=31)
+    (pts, npts, recs), (opts, onpts, orecs) = _simulate_both(engine, objs, rays, 100.0, 10)
+    assert np.array_equal(npts, onpts)
+    assert_records_equal(recs, orecs, "far planes")
+    assert np.array_equal(pts, opts)
+
+
+def test_grazing_rays_stress_filter(engine):
+    """Rays aimed at sphere limbs (|disc| tiny): the conservative filter must never drop a pair the exact test accepts."""
+    rng = np.random.default_rng(5)
+    objs = random_scene(400, 0, seed=21, extent=(60.0, 30.0, 60.0))
+    pos, rad = objs["position"].astype(np.float64), objs["shape_param"][:, 0].astype(np.float64)
+    n = 30000
+    k = rng.integers(0, len(objs), n)
+    o = rng.uniform(-1, 1, size=(n, 3)) * np.array([150.0, 80.0, 150.0])
+    to_c = pos[k] - o
+    dist = np.linalg.norm(to_c, axis=1, keepdims=True)
+    u = np.cross(to_c, rng.normal(size=(n, 3)))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    # aim at a point on the limb, within +-1e-5 relative of the radius
+    limb = pos[k] + u * (rad[k, None] * (1 + rng.uniform(-1e-5, 1e-5, size=(n, 1))))
+    d = limb - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = make_rays(o.astype(np.float32), d.astype(np.float32))
+    (pts, npts, recs), (opts, onpts, orecs) = _simulate_both(engine, objs, rays, 50.0, 4)
+    assert np.array_equal(npts, onpts)
+    assert_records_equal(recs, orecs, "grazing")

