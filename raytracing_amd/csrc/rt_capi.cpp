@@ -4,6 +4,7 @@
 // gfx950 kernels or fails with an error code.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -25,6 +26,8 @@ struct Context {
     unsigned next_counter = 0;
     unsigned long long* fb_q = nullptr;  // fixed-point framebuffer scratch (grow-only)
     size_t fb_q_bytes = 0;
+    uint32_t* secq = nullptr;  // continuing-ray rings of the pinhole kernel (grow-only)
+    size_t secq_bytes = 0;
 };
 Context g_ctx;
 constexpr unsigned kCounterRing = 1024;
@@ -69,6 +72,7 @@ hipError_t upload(const std::vector<T>& v, const T** out)
 struct rt_scene {
     rt::DevScene dev{};
     std::vector<void*> allocations;
+    std::vector<float4> host_spheres;  // {p, r} per sphere, for per-call constants that depend on the generator
 };
 
 namespace {
@@ -112,18 +116,48 @@ int check_common(const rt_scene* scene, RtSettings st)
     return RT_OK;
 }
 
-int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream)
+int g_scan_mode = 0;
+
+// Projector + single LDS tile + default filter: the shared-origin kernel; everything else: the general kernel.
+bool use_pinhole(const rt::TraceParams& p)
+{
+    if (getenv("RT_HIP_NO_PINHOLE")) return false;  // tuning / A-B knob
+    return !p.rays && p.gen.kind == RT_GEN_PROJECTOR && p.scan_mode == 0 && p.sc.n_sph_pad <= (uint32_t)rt::kTileSpheres &&
+           p.fb_q != nullptr;
+}
+
+int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream, const rt_scene* scene)
 {
     unsigned idx = g_ctx.next_counter++ % kCounterRing;
     p.next_unit = g_ctx.counters + idx;
     p.total_segments = d_total;
     HIP_TRY(hipMemsetAsync(p.next_unit, 0, sizeof(unsigned long long), stream));
     if (d_total) HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), stream));
-    HIP_TRY(rt::launch_trace(p, g_ctx.n_cu, stream));
+    if (use_pinhole(p)) {
+        // margin of the shared-origin filter: 64 u * max_j(|p_j - O|^2 + r_j^2), rounded up
+        double c2 = 0.0;
+        for (const float4& s : scene->host_spheres) {
+            const double x = (double)s.x - p.gen.a[0], y = (double)s.y - p.gen.a[1], z = (double)s.z - p.gen.a[2];
+            const double v = x * x + y * y + z * z + (double)s.w * s.w;
+            if (v > c2) c2 = v;
+        }
+        p.prim_margin = (float)(c2 * 64.0 * 0x1p-24 * (1.0 + 1e-6));
+        const size_t need = rt::pinhole_secq_bytes(p, g_ctx.n_cu);
+        if (need > g_ctx.secq_bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(g_ctx.secq);
+            g_ctx.secq = nullptr;
+            g_ctx.secq_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&g_ctx.secq, need));
+            g_ctx.secq_bytes = need;
+        }
+        p.secq = g_ctx.secq;
+        HIP_TRY(rt::launch_pinhole(p, g_ctx.n_cu, stream));
+    } else {
+        HIP_TRY(rt::launch_trace(p, g_ctx.n_cu, stream));
+    }
     return RT_OK;
 }
-
-int g_scan_mode = 0;
 
 }  // namespace
 
@@ -145,6 +179,7 @@ int rt_hip_init(int device_ordinal)
     if (g_ctx.ready && g_ctx.device != device_ordinal) {
         (void)hipFree(g_ctx.counters);
         (void)hipFree(g_ctx.fb_q);
+        (void)hipFree(g_ctx.secq);
         g_ctx = Context{};
     }
     if (!g_ctx.ready) {
@@ -163,6 +198,7 @@ void rt_hip_shutdown(void)
         (void)hipDeviceSynchronize();
         (void)hipFree(g_ctx.counters);
         (void)hipFree(g_ctx.fb_q);
+        (void)hipFree(g_ctx.secq);
         g_ctx = Context{};
     }
 }
@@ -255,6 +291,7 @@ int rt_hip_scene_create(const RtObject* objects, uint64_t n_objects, rt_scene** 
     d.n_pl = (uint32_t)pl_pos.size();
     d.n_obj = (uint32_t)n_objects;
     d.c2max = c2max_f;
+    s->host_spheres.assign(sph_exact.begin(), sph_exact.begin() + n_sph);
     *out_scene = s;
     return RT_OK;
 }
@@ -300,7 +337,7 @@ int rt_hip_simulate_dev(const rt_scene* scene, const RtRay* d_rays, uint64_t n_r
     p.n_points = d_n_points;
     p.records = d_records;
     p.scan_mode = g_scan_mode;
-    return enqueue(p, (unsigned long long*)d_total_segments, (hipStream_t)stream);
+    return enqueue(p, (unsigned long long*)d_total_segments, (hipStream_t)stream, scene);
 }
 
 int rt_hip_simulate(const rt_scene* scene, const RtRay* rays, uint64_t n_rays, RtSettings settings, uint64_t seed,
@@ -405,7 +442,7 @@ int rt_hip_render_dev(const rt_scene* scene, const RtRayGenerator* gen, uint32_t
     p.first_t = d_first_t;
     p.seg_count = d_seg_count;
     p.scan_mode = g_scan_mode;
-    if (int rc = enqueue(p, (unsigned long long*)d_total_segments, hs)) return rc;
+    if (int rc = enqueue(p, (unsigned long long*)d_total_segments, hs, scene)) return rc;
     HIP_TRY(rt::launch_finalize(g_ctx.fb_q, d_fb, (uint64_t)cell_count * 3, spp, hs));
     return RT_OK;
 }

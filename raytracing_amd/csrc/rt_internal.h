@@ -58,10 +58,19 @@ struct TraceParams {
     unsigned long long* total_segments;  // accumulated with atomics; zeroed by the launcher
     unsigned long long* next_unit;       // work counter; zeroed by the launcher
     int scan_mode;                       // 0 = conservative cull, 1 = exact discriminant filter
+    // pinhole kernel only
+    uint32_t* secq;     // per-wave rings of continuing rays: [grid waves][kSecFields][kSecCap] dwords
+    float prim_margin;  // >= 64 u * max_j(|p_j - O|^2 + r_j^2): margin of the shared-origin filter
 };
+
+constexpr unsigned kSecCap = 256;    // entries per wave ring (a primary step adds <= 128 to a residue < 128)
+constexpr unsigned kSecFields = 10;  // o.xyz d.xyz ior cell sample bounce
 
 // Launches the trace kernel on `stream`; d_work = {unsigned long long total_segments; unsigned next_cell} scratch.
 hipError_t launch_trace(const TraceParams& p, int n_cu, hipStream_t stream);
+// Shared-origin (Projector) specialisation; needs n_sph_pad <= kTileSpheres. secq must hold pinhole_secq_bytes().
+hipError_t launch_pinhole(const TraceParams& p, int n_cu, hipStream_t stream);
+size_t pinhole_secq_bytes(const TraceParams& p, int n_cu);
 hipError_t launch_finalize(const unsigned long long* fb_q, float* fb, uint64_t n_values, uint32_t spp, hipStream_t stream);
 
 }  // namespace rt

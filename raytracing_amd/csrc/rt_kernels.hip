@@ -21,195 +21,13 @@
 // Everything outside the filter is compiled without FP contraction (-ffp-contract=off) so that it rounds
 // exactly like the reference's scalar f32 code; the filter uses explicit fmaf and is protected by the
 // error bound derived in DESIGN.md ("Conservative filter").
-#include "rt_internal.h"
+#include "rt_device.h"
 
 #include <cstdlib>
 
 namespace rt {
 
 namespace {
-
-constexpr float kTMin = 0.001f;       // scene.rs:54
-constexpr float kReorigin = 0.001f;   // scene.rs:97
-constexpr float kCullKappaU = 7.62939453125e-06f;  // 128 * 2^-24 (needs >= 94 u)
-constexpr unsigned kQueueCap = 256;   // per-wave candidate ring (entries), power of two
-constexpr unsigned long long kNoHit = ~0ull;
-
-struct F3 {
-    float x, y, z;
-};
-__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
-__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
-__device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ F3 operator*(float s, F3 a) { return f3(s * a.x, s * a.y, s * a.z); }
-__device__ __forceinline__ F3 operator/(F3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
-__device__ __forceinline__ float dot(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-__device__ __forceinline__ F3 normalize(F3 a)
-{
-    float len = __builtin_sqrtf(dot(a, a));
-    float rcp = 1.0f / len;
-    return a * rcp;
-}
-
-// scene.rs:9-11
-__device__ __forceinline__ F3 reflect(F3 i, F3 n) { return i - 2.0f * dot(i, n) * n; }
-// scene.rs:14-27
-__device__ __forceinline__ bool refract(F3 i, F3 n, float ratio, F3& out)
-{
-    float cos_theta = __builtin_fminf(dot(-i, n), 1.0f);
-    float sin2 = 1.0f - cos_theta * cos_theta;
-    if (ratio * ratio * sin2 > 1.0f) return false;
-    F3 perp = ratio * (i + cos_theta * n);
-    F3 par = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot(perp, perp))) * n;
-    out = normalize(perp + par);
-    return true;
-}
-
-// Philox4x32-10, counter (path lo, path hi, bounce, tag), key = seed; rand 0.8 Standard f32 mapping.
-__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t path_id, uint32_t bounce)
-{
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    uint32_t c0 = (uint32_t)path_id, c1 = (uint32_t)(path_id >> 32), c2 = bounce, c3 = 0x52415953u;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return (float)(c0 >> 8) * (1.0f / 16777216.0f);
-}
-
-__device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-__device__ __forceinline__ unsigned mbcnt64(unsigned long long m)
-{
-    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-}
-// LDS traffic between lanes of one wave: order the DS instructions, nothing leaves the CU.
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ unsigned long long pack_key(float t, int32_t obj) { return ((unsigned long long)__float_as_uint(t) << 32) | (uint32_t)obj; }
-
-// First element of the reference's hit list for Transform(Sphere) with rotation 0, as a (t, found) pair:
-// transform.rs:22-23 (local origin = o - position exactly, local direction = d), sphere.rs:13-66.
-__device__ __forceinline__ bool sphere_first_t(F3 o, F3 d, float a, F3 pos, float radius, float& t_out)
-{
-    F3 lo = o - pos;
-    float half_b = dot(lo, d);
-    float c = dot(lo, lo) - radius * radius;
-    float disc = half_b * half_b - a * c;
-    if (disc < 0.0f) return false;
-    float sqrtd = __builtin_sqrtf(disc);
-    float t1 = (-half_b - sqrtd) / a;
-    if (t1 > kTMin && t1 < __builtin_inff()) {
-        t_out = t1;
-        return true;
-    }
-    if (disc > 1e-6f) {
-        float t2 = (-half_b + sqrtd) / a;
-        if (t2 > kTMin && t2 < __builtin_inff()) {
-            t_out = t2;
-            return true;
-        }
-    }
-    return false;
-}
-
-template <int R>
-struct WaveLds {
-    float stash[7][R * 64];            // o.xyz, d.xyz, a per slot
-    unsigned long long best[R * 64];   // (t bits << 32 | obj id), kNoHit when empty
-    unsigned queue[kQueueCap];         // (sphere index << 8) | slot
-};
-
-// Confirm up to 64 queued (slot, sphere) pairs with the exact operation sequence.
-template <int R>
-__device__ __forceinline__ void confirm_batch(WaveLds<R>& w, const DevScene& sc, unsigned head, unsigned count, unsigned lane)
-{
-    if (lane < count) {
-        unsigned e = w.queue[(head + lane) & (kQueueCap - 1)];
-        unsigned slot = e & 255u, j = e >> 8;
-        if (j < sc.n_sph) {
-            F3 o = f3(w.stash[0][slot], w.stash[1][slot], w.stash[2][slot]);
-            F3 d = f3(w.stash[3][slot], w.stash[4][slot], w.stash[5][slot]);
-            float a = w.stash[6][slot];
-            float4 s = sc.sph_exact[j];
-            float t;
-            if (sphere_first_t(o, d, a, f3(s.x, s.y, s.z), s.w, t)) atomicMin(&w.best[slot], pack_key(t, sc.sph_obj[j]));
-        }
-    }
-}
-
-template <int R>
-__device__ __forceinline__ void push_candidates(WaveLds<R>& w, const DevScene& sc, unsigned long long mask, unsigned slot_base,
-                                                unsigned j, unsigned& head, unsigned& tail, unsigned lane)
-{
-    unsigned pos = tail + mbcnt64(mask);
-    if ((mask >> lane) & 1ull) w.queue[pos & (kQueueCap - 1)] = (j << 8) | (slot_base + lane);
-    tail += (unsigned)__builtin_popcountll(mask);
-    if (tail - head >= 64u) {
-        wave_lds_sync();
-        confirm_batch<R>(w, sc, head, 64u, lane);
-        head += 64u;
-        wave_lds_sync();
-    }
-}
-
-struct Slot {
-    F3 o, d;
-    float ior;
-    unsigned long long accx, accy, accz;  // fixed-point (2^-24) sums of the unit's path values
-    uint32_t m;           // work item (cell / ray)
-    uint32_t sample;      // current sample index
-    uint32_t sample_end;  // one past the unit's last sample
-    uint32_t bounce;
-    uint32_t segs;    // segments of the current cell
-    uint32_t np;      // polyline vertices written
-    bool live;        // carries a ray through the next scan
-};
-
-__device__ __forceinline__ void primary_ray(const TraceParams& p, uint32_t m, F3& o, F3& d, float& ior)
-{
-    if (p.rays) {
-        const RtRay r = p.rays[m];
-        o = f3(r.origin[0], r.origin[1], r.origin[2]);
-        d = f3(r.direction[0], r.direction[1], r.direction[2]);
-        ior = r.current_ior;
-        return;
-    }
-    const DevGen& g = p.gen;
-    uint64_t cell = p.cell_begin + (uint64_t)m * p.cell_step;
-    uint32_t i = (uint32_t)(cell / g.count_v), j = (uint32_t)(cell % g.count_v);
-    F3 us = f3(g.u_step[0], g.u_step[1], g.u_step[2]), vs = f3(g.v_step[0], g.v_step[1], g.v_step[2]);
-    F3 a = f3(g.a[0], g.a[1], g.a[2]);
-    ior = g.current_ior;
-    if (g.kind == RT_GEN_PARALLEL_GRID) {
-        o = (a + ((float)i * us)) + ((float)j * vs);
-        d = f3(g.dir_n[0], g.dir_n[1], g.dir_n[2]);
-    } else {
-        F3 corner = f3(g.corner[0], g.corner[1], g.corner[2]);
-        F3 target = (corner + ((float)i * us)) + ((float)j * vs);
-        o = a;
-        d = normalize(target - a);
-    }
-}
-
-// DESIGN.md "path value" (no reference counterpart).
-__device__ __forceinline__ F3 sky(F3 d)
-{
-    float w = 0.5f * (d.y + 1.0f);
-    float k = 1.0f - w;
-    return f3(k + w * 0.5f, k + w * 0.7f, k + w);
-}
 
 template <int R, int MODE>
 __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams p)
@@ -308,25 +126,24 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
         }
 
         // ---- 2. per-segment constants ----
-        float a_[R];
-        F3 dh[R], pp[R];
-        float nod[R], s0[R];
+        ScanConsts<R> c;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const F3 o = s[r].o, d = s[r].d;
-            a_[r] = dot(d, d);
+            const float a = dot(d, d);
             const unsigned slot = r * 64 + lane;
             w.stash[0][slot] = o.x; w.stash[1][slot] = o.y; w.stash[2][slot] = o.z;
             w.stash[3][slot] = d.x; w.stash[4][slot] = d.y; w.stash[5][slot] = d.z;
-            w.stash[6][slot] = a_[r];
+            w.stash[6][slot] = a;
             w.best[slot] = kNoHit;
-            float rs = 1.0f / __builtin_sqrtf(a_[r]);
-            dh[r] = d * rs;
-            nod[r] = -dot(o, dh[r]);
+            float rs = 1.0f / __builtin_sqrtf(a);
+            c.dh[r] = d * rs;
+            c.nod[r] = -dot(o, c.dh[r]);
             float oo = dot(o, o);
             float margin = kCullKappaU * (oo + sc.c2max);
-            s0[r] = s[r].live ? (oo - margin) : __builtin_inff();
-            pp[r] = f3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z);
+            c.s0[r] = s[r].live ? (oo - margin) : __builtin_inff();
+            c.pp[r] = f3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z);
+            c.o[r] = o; c.d[r] = d; c.a[r] = a; c.live[r] = s[r].live;
         }
         unsigned head = 0, tail = 0;
         wave_lds_sync();
@@ -341,46 +158,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
                 __syncthreads();
                 if (wave_done) continue;
             }
-            const unsigned jbase = t_i * kTileSpheres;
-            for (unsigned j = 0; j < count; j += kUnroll) {
-                float4 sp[kUnroll];
-#pragma unroll
-                for (int u = 0; u < kUnroll; ++u) sp[u] = tile[j + u];
-                unsigned long long mk[kUnroll][R];
-                unsigned long long any = 0;
-#pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        bool pass;
-                        if (MODE == 0) {
-                            float h = __builtin_fmaf(sp[u].x, dh[r].x, __builtin_fmaf(sp[u].y, dh[r].y, __builtin_fmaf(sp[u].z, dh[r].z, nod[r])));
-                            float S = __builtin_fmaf(sp[u].x, pp[r].x, __builtin_fmaf(sp[u].y, pp[r].y, __builtin_fmaf(sp[u].z, pp[r].z, s0[r])));
-                            float q = __builtin_fmaf(h, h, -S);
-                            pass = q >= sp[u].w;
-                        } else {
-                            // exact discriminant as the filter (sphere.rs:13-18); padding/dead slots never pass
-                            float4 se = sc.sph_exact[jbase + j + u];
-                            F3 lo = s[r].o - f3(se.x, se.y, se.z);
-                            float half_b = dot(lo, s[r].d);
-                            float c = dot(lo, lo) - se.w * se.w;
-                            float disc = half_b * half_b - a_[r] * c;
-                            pass = s[r].live && (jbase + j + u < sc.n_sph) && !(disc < 0.0f);
-                        }
-                        mk[u][r] = __ballot(pass);
-                        any |= mk[u][r];
-                    }
-                }
-                if (any) {
-#pragma unroll
-                    for (int u = 0; u < kUnroll; ++u) {
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            if (mk[u][r]) push_candidates<R>(w, sc, mk[u][r], r * 64, jbase + j + u, head, tail, lane);
-                        }
-                    }
-                }
-            }
+            scan_tile<R, (MODE == 0 ? 0 : 2)>(tile, count, t_i * kTileSpheres, c, w, sc, head, tail, lane);
         }
         if (wave_done) continue;  // multi-tile mode: this wave only keeps the barriers company
 
@@ -396,19 +174,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             const unsigned slot = r * 64 + lane;
             unsigned long long key = w.best[slot];
             const F3 o = s[r].o, d = s[r].d;
-            for (unsigned k = 0; k < sc.n_pl; ++k) {
-                // Transform(Plane) with rotation 0: transform.rs:22-23, plane.rs:14-27
-                float4 pp4 = sc.pl_pos[k], pn4 = sc.pl_nrm[k];
-                F3 n = f3(pn4.x, pn4.y, pn4.z);
-                F3 lo = o - f3(pp4.x, pp4.y, pp4.z);
-                float denom = dot(n, d);
-                if (__builtin_fabsf(denom) < 1e-6f) continue;
-                float t = dot(f3(0.0f, 0.0f, 0.0f) - lo, n) / denom;
-                if (t >= kTMin && t < __builtin_inff()) {
-                    unsigned long long kk = pack_key(t, sc.pl_obj[k]);
-                    key = kk < key ? kk : key;
-                }
-            }
+            key = planes_min_key(sc, o, d, key);
             ++s[r].segs;
             ++my_segments;
             const uint32_t b = s[r].bounce;

@@ -1,0 +1,315 @@
+// rt_pinhole.hip — the render loop specialised for RayGeneratorConfig::Projector (scene_config.rs:84-108):
+// every primary ray leaves the same origin O, so the primary closest-hit scan (77 % of all segments on the C2
+// workload) needs only  h = (p - O) . d^  and one compare per sphere:  |h| >= sK,  sK = sqrt(|p-O|^2 - r^2 - margin)
+// precomputed per sphere when the block starts.  That is 4 VALU instructions per test instead of 8.
+//
+// Rays that hit something leave the primary stream: the scatter result (scene.rs:68-97) is appended to a
+// wave-private ring of continuing rays, and whenever a full wave of them (64*R) has collected, the wave runs
+// one general scan step for them (same code as trace_kernel).  Both step kinds therefore run with every lane
+// busy.  Path values of primary misses are summed per work unit in registers; continuing paths add their
+// value and segment count with global atomics when they end (fixed-point sums: order-independent).
+#include "rt_device.h"
+
+#include <cstdlib>
+
+namespace rt {
+namespace {
+
+
+constexpr int kPinThreads = 512;  // 8 waves share the two LDS tables; 2 blocks per CU = 4 waves per SIMD
+
+template <int R>
+__global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TraceParams p)
+{
+    extern __shared__ float4 tiles[];  // [n_sph_pad] general {p, K}  then  [n_sph_pad] pinhole {p - O, sK}
+    __shared__ WaveLds<R> wl[kPinThreads / 64];
+
+    const unsigned lane = lane_id();
+    const unsigned wave = threadIdx.x >> 6;
+    WaveLds<R>& w = wl[wave];
+    const DevScene& sc = p.sc;
+    const unsigned n_pad = sc.n_sph_pad;
+    float4* tileG = tiles;
+    float4* tileP = tiles + n_pad;
+    const F3 O = f3(p.gen.a[0], p.gen.a[1], p.gen.a[2]);
+
+    for (unsigned k = threadIdx.x; k < n_pad; k += kPinThreads) {
+        tileG[k] = sc.sph_cull[k];
+        float4 e = sc.sph_exact[k];
+        float4 t4;
+        if (k < sc.n_sph) {
+            // p' = fl(p - O) is exactly minus the reference's local origin fl(O - p) (transform.rs:22), so K' below is
+            // exact for the operands every later test uses.
+            const float px = e.x - O.x, py = e.y - O.y, pz = e.z - O.z;
+            const double K = ((double)px * px + (double)py * py + (double)pz * pz) - (double)e.w * e.w;
+            const double Kq = K - (double)p.prim_margin;
+            const float sK = (Kq <= 0.0) ? -1.0f : (float)(__builtin_sqrt(Kq) * (1.0 - 0x1p-22));
+            t4 = make_float4(px, py, pz, sK);
+        } else {
+            t4 = make_float4(0.f, 0.f, 0.f, __builtin_inff());
+        }
+        tileP[k] = t4;
+    }
+    __syncthreads();
+
+    // per-wave ring of continuing rays (global memory, only this wave touches it)
+    const unsigned gwave = blockIdx.x * (kPinThreads / 64) + wave;
+    uint32_t* ring = p.secq + (size_t)gwave * kSecFields * kSecCap;
+    unsigned sec_count = 0;  // wave-uniform
+
+    // primary feeder slots: one work unit (cell, sample block) each
+    uint32_t um[R], usample[R], uend[R], usegs[R];
+    unsigned long long ax[R], ay[R], az[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        um[r] = 0xffffffffu;
+        usample[r] = uend[r] = usegs[r] = 0;
+        ax[r] = ay[r] = az[r] = 0;
+    }
+    unsigned long long my_segments = 0;
+    bool exhausted = false, prim_done = false;
+    const unsigned long long total_units = (unsigned long long)p.cell_count * p.units_per_cell;
+    const uint32_t max_b = p.st.max_bounces;
+
+    for (;;) {
+        const bool do_sec = sec_count >= 64u * R || (prim_done && sec_count > 0);
+        if (!do_sec && prim_done) break;
+
+        ScanConsts<R> c;
+        F3 ro[R], rd[R];
+        float rior[R];
+        uint32_t rm[R], rsample[R], rb[R];
+        bool live[R];
+        unsigned head = 0, tail = 0;
+
+        if (!do_sec) {
+            // ================= primary step =================
+            bool any_live = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                bool need_unit = (um[r] == 0xffffffffu);
+                unsigned long long need = __ballot(need_unit);
+                if (need && !exhausted) {
+                    unsigned cnt = (unsigned)__builtin_popcountll(need);
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(p.next_unit, (unsigned long long)cnt);
+                    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
+                           __builtin_amdgcn_readfirstlane((unsigned)base);
+                    if (base + cnt >= total_units) exhausted = true;
+                    if (need_unit) {
+                        unsigned long long unit = base + mbcnt64(need);
+                        if (unit < total_units) {
+                            uint32_t m = (uint32_t)(unit / p.units_per_cell);
+                            uint32_t k = (uint32_t)(unit - (unsigned long long)m * p.units_per_cell);
+                            um[r] = m;
+                            usample[r] = k * p.unit_samples;
+                            uint32_t e = usample[r] + p.unit_samples;
+                            uend[r] = e < p.spp ? e : p.spp;
+                            usegs[r] = 0;
+                            ax[r] = ay[r] = az[r] = 0;
+                        }
+                    }
+                }
+                live[r] = (um[r] != 0xffffffffu);
+                any_live |= (__ballot(live[r]) != 0ull);
+            }
+            if (!any_live) {
+                prim_done = true;
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                rm[r] = um[r];
+                rsample[r] = usample[r];
+                rb[r] = 0;
+                ro[r] = O;
+                rd[r] = f3(0.f, 0.f, 0.f);
+                rior[r] = p.gen.current_ior;
+                if (live[r]) primary_ray(p, um[r], ro[r], rd[r], rior[r]);
+                const float a = dot(rd[r], rd[r]);
+                const unsigned slot = r * 64 + lane;
+                w.stash[0][slot] = ro[r].x; w.stash[1][slot] = ro[r].y; w.stash[2][slot] = ro[r].z;
+                w.stash[3][slot] = rd[r].x; w.stash[4][slot] = rd[r].y; w.stash[5][slot] = rd[r].z;
+                w.stash[6][slot] = a;
+                w.best[slot] = kNoHit;
+                const float rs = 1.0f / __builtin_sqrtf(a);
+                const float nanv = __builtin_nanf("");
+                c.dh[r] = live[r] ? rd[r] * rs : f3(nanv, nanv, nanv);  // NaN never passes |h| >= sK
+            }
+            wave_lds_sync();
+            scan_tile<R, 1>(tileP, n_pad, 0, c, w, sc, head, tail, lane);
+        } else {
+            // ================= continuing-ray step =================
+            const unsigned n_pop = sec_count < 64u * R ? sec_count : 64u * R;
+            const unsigned base = sec_count - n_pop;
+            sec_count = base;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const unsigned idx = r * 64 + lane;
+                live[r] = idx < n_pop;
+                const unsigned e = base + (live[r] ? idx : 0u);
+                float v[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) v[k] = __uint_as_float(ring[k * kSecCap + e]);
+                ro[r] = f3(v[0], v[1], v[2]);
+                rd[r] = f3(v[3], v[4], v[5]);
+                rior[r] = v[6];
+                rm[r] = ring[7 * kSecCap + e];
+                rsample[r] = ring[8 * kSecCap + e];
+                rb[r] = ring[9 * kSecCap + e];
+                const F3 o = ro[r], d = rd[r];
+                const float a = dot(d, d);
+                const unsigned slot = r * 64 + lane;
+                w.stash[0][slot] = o.x; w.stash[1][slot] = o.y; w.stash[2][slot] = o.z;
+                w.stash[3][slot] = d.x; w.stash[4][slot] = d.y; w.stash[5][slot] = d.z;
+                w.stash[6][slot] = a;
+                w.best[slot] = kNoHit;
+                const float rs = 1.0f / __builtin_sqrtf(a);
+                c.dh[r] = d * rs;
+                c.nod[r] = -dot(o, c.dh[r]);
+                const float oo = dot(o, o);
+                const float margin = kCullKappaU * (oo + sc.c2max);
+                c.s0[r] = live[r] ? (oo - margin) : __builtin_inff();
+                c.pp[r] = f3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z);
+            }
+            wave_lds_sync();
+            scan_tile<R, 0>(tileG, n_pad, 0, c, w, sc, head, tail, lane);
+        }
+
+        // ---- drain the candidate queue, resolve ----
+        wave_lds_sync();
+        if (tail != head) confirm_batch<R>(w, sc, head, tail - head, lane);
+        wave_lds_sync();
+
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            bool push = false;
+            Shade h;
+            h.o_next = ro[r]; h.dn = rd[r]; h.ior = rior[r];
+            if (live[r]) {
+                const unsigned slot = r * 64 + lane;
+                unsigned long long key = planes_min_key(sc, ro[r], rd[r], w.best[slot]);
+                ++my_segments;
+                const uint32_t b = rb[r];
+                const uint64_t path_id = (p.cell_begin + (uint64_t)rm[r] * p.cell_step) * (uint64_t)p.spp + rsample[r];
+                bool ended = false;
+                F3 value = f3(0.f, 0.f, 0.f);
+                if (key != kNoHit) {
+                    h = shade_hit(sc, ro[r], rd[r], rior[r], key, p.seed, path_id, b);
+                    if (b == 0 && rsample[r] == 0) {
+                        if (p.first_id) p.first_id[rm[r]] = h.obj;
+                        if (p.first_t) p.first_t[rm[r]] = h.t;
+                    }
+                    if (b + 1 == max_b) ended = true;  // bounce budget exhausted: value 0
+                    else push = true;
+                } else {
+                    if (b == 0 && rsample[r] == 0) {
+                        if (p.first_id) p.first_id[rm[r]] = -1;
+                        if (p.first_t) p.first_t[rm[r]] = __builtin_inff();
+                    }
+                    value = sky(rd[r]);
+                    ended = true;
+                }
+                if (!do_sec) {
+                    // the feeder owns the unit's register sums; a primary miss ends the path here
+                    ++usegs[r];
+                    if (ended) {
+                        ax[r] += quantize(value.x);
+                        ay[r] += quantize(value.y);
+                        az[r] += quantize(value.z);
+                    }
+                    ++usample[r];
+                    if (usample[r] == uend[r]) {
+                        unsigned long long* q = p.fb_q + (uint64_t)um[r] * 3;
+                        if (ax[r]) atomicAdd(q + 0, ax[r]);
+                        if (ay[r]) atomicAdd(q + 1, ay[r]);
+                        if (az[r]) atomicAdd(q + 2, az[r]);
+                        if (p.seg_count) atomicAdd(p.seg_count + um[r], usegs[r]);
+                        um[r] = 0xffffffffu;
+                    }
+                } else if (ended) {
+                    // a continuing path ends: it has run b segments after its primary one
+                    unsigned long long* q = p.fb_q + (uint64_t)rm[r] * 3;
+                    const unsigned long long qx = quantize(value.x), qy = quantize(value.y), qz = quantize(value.z);
+                    if (qx) atomicAdd(q + 0, qx);
+                    if (qy) atomicAdd(q + 1, qy);
+                    if (qz) atomicAdd(q + 2, qz);
+                    if (p.seg_count) atomicAdd(p.seg_count + rm[r], b);
+                }
+            }
+            // append continuing rays to the ring (wave-uniform control flow)
+            const unsigned long long pm = __ballot(push);
+            if (pm) {
+                const unsigned e = sec_count + mbcnt64(pm);
+                if (push) {
+                    ring[0 * kSecCap + e] = __float_as_uint(h.o_next.x);
+                    ring[1 * kSecCap + e] = __float_as_uint(h.o_next.y);
+                    ring[2 * kSecCap + e] = __float_as_uint(h.o_next.z);
+                    ring[3 * kSecCap + e] = __float_as_uint(h.dn.x);
+                    ring[4 * kSecCap + e] = __float_as_uint(h.dn.y);
+                    ring[5 * kSecCap + e] = __float_as_uint(h.dn.z);
+                    ring[6 * kSecCap + e] = __float_as_uint(h.ior);
+                    ring[7 * kSecCap + e] = rm[r];
+                    ring[8 * kSecCap + e] = rsample[r];
+                    ring[9 * kSecCap + e] = rb[r] + 1;
+                }
+                sec_count += (unsigned)__builtin_popcountll(pm);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+
+    if (p.total_segments) {
+        unsigned long long v = my_segments;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0 && v) atomicAdd(p.total_segments, v);
+    }
+}
+
+constexpr int kR = 2;
+
+int pinhole_blocks_per_cu(size_t dyn_bytes)
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pinhole_kernel<kR>, kPinThreads, dyn_bytes) != hipSuccess || n < 1) n = 1;
+    if (const char* e = getenv("RT_HIP_BLOCKS_PER_CU")) {  // tuning knob
+        int v = atoi(e);
+        if (v >= 1 && v <= 8) n = v;
+    }
+    return n;
+}
+
+unsigned pinhole_grid(const TraceParams& p, int n_cu)
+{
+    const size_t dyn = (size_t)p.sc.n_sph_pad * sizeof(float4) * 2;
+    const uint64_t slots_per_block = (uint64_t)kPinThreads * kR;
+    const uint64_t want = ((uint64_t)p.cell_count * p.units_per_cell + slots_per_block - 1) / slots_per_block;
+    const uint64_t cap = (uint64_t)n_cu * pinhole_blocks_per_cu(dyn);
+    unsigned blocks = (unsigned)(want < cap ? want : cap);
+    return blocks ? blocks : 1;
+}
+
+}  // namespace
+
+size_t pinhole_secq_bytes(const TraceParams& p, int n_cu)
+{
+    return (size_t)pinhole_grid(p, n_cu) * (kPinThreads / 64) * kSecFields * kSecCap * sizeof(uint32_t);
+}
+
+hipError_t launch_pinhole(const TraceParams& p, int n_cu, hipStream_t stream)
+{
+    const size_t dyn = (size_t)p.sc.n_sph_pad * sizeof(float4) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)pinhole_kernel<kR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(kTileSpheres * sizeof(float4) * 2));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((pinhole_kernel<kR>), dim3(pinhole_grid(p, n_cu)), dim3(kPinThreads), dyn, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace rt
