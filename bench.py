@@ -162,7 +162,7 @@ def main():
             },
             "roofline": {
                 "bound": "valu_fp32",
-                "kernel": "trace_kernel",
+                "kernel": "pinhole_kernel (Projector render loop; general trace_kernel for other generators)",
                 "achieved": achieved,
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",

@@ -83,14 +83,11 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed, float
                 : "v"(b), "v"(a), "s"(sc));
             acc |= (m0 | m1) | (m2 | m3);
         }
-        else if (MODE == 13) {  // VOPC e32 -> vcc, then s_or (the cheapest compare form?)
+        else if (MODE == 13) {  // VOPC e32 -> vcc only
             asm volatile(
-                "v_fma_f32 %0, %0, %5, %6\n v_cmp_ge_f32_e32 vcc, %0, %1\n s_or_b64 %4, %4, vcc\n"
-                "v_fma_f32 %1, %1, %5, %6\n v_cmp_ge_f32_e32 vcc, %1, %2\n s_or_b64 %4, %4, vcc\n"
-                "v_fma_f32 %2, %2, %5, %6\n v_cmp_ge_f32_e32 vcc, %2, %3\n s_or_b64 %4, %4, vcc\n"
-                "v_fma_f32 %3, %3, %5, %6\n v_cmp_ge_f32_e32 vcc, %3, %0\n s_or_b64 %4, %4, vcc\n"
-                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(acc)
-                : "v"(b), "v"(a) : "vcc");
+                "v_cmp_ge_f32_e32 vcc, %0, %1\n v_cmp_ge_f32_e32 vcc, %1, %2\n v_cmp_ge_f32_e32 vcc, %2, %3\n v_cmp_ge_f32_e32 vcc, %3, %0\n"
+                "v_cmp_ge_f32_e32 vcc, %0, %2\n v_cmp_ge_f32_e32 vcc, %1, %3\n v_cmp_ge_f32_e32 vcc, %2, %0\n v_cmp_ge_f32_e32 vcc, %3, %1\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : : "vcc");
         } else if (MODE == 14) {  // e64 compare with |abs| modifier, VGPR operands
             unsigned long long m0, m1, m2, m3;
             asm volatile(
@@ -127,6 +124,41 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed, float
                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3)
                 : "v"(b), "v"(a));
             acc |= (m0 | m1) | (m2 | m3);
+        }
+        else if (MODE == 19) {  // VOPC e32 -> vcc, s_or into an accumulator after each
+            unsigned long long m0 = 0;
+            asm volatile(
+                "v_cmp_ge_f32_e32 vcc, %0, %1\n s_or_b64 %4, %4, vcc\n v_cmp_ge_f32_e32 vcc, %1, %2\n s_or_b64 %4, %4, vcc\n"
+                "v_cmp_ge_f32_e32 vcc, %2, %3\n s_or_b64 %4, %4, vcc\n v_cmp_ge_f32_e32 vcc, %3, %0\n s_or_b64 %4, %4, vcc\n"
+                "v_cmp_ge_f32_e32 vcc, %0, %2\n s_or_b64 %4, %4, vcc\n v_cmp_ge_f32_e32 vcc, %1, %3\n s_or_b64 %4, %4, vcc\n"
+                "v_cmp_ge_f32_e32 vcc, %2, %0\n s_or_b64 %4, %4, vcc\n v_cmp_ge_f32_e32 vcc, %3, %1\n s_or_b64 %4, %4, vcc\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(m0) : : "vcc");
+            acc |= m0;
+        } else if (MODE == 20) {  // integer compare e64
+            unsigned long long m0, m1, m2, m3;
+            asm volatile(
+                "v_cmp_ge_u32_e64 %4, %0, %1\n v_cmp_ge_u32_e64 %5, %1, %2\n v_cmp_ge_u32_e64 %6, %2, %3\n v_cmp_ge_u32_e64 %7, %3, %0\n"
+                "v_cmp_ge_u32_e64 %4, %0, %2\n v_cmp_ge_u32_e64 %5, %1, %3\n v_cmp_ge_u32_e64 %6, %2, %0\n v_cmp_ge_u32_e64 %7, %3, %1\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3));
+            acc |= (m0 | m1) | (m2 | m3);
+        } else if (MODE == 21) {  // v_max_f32 VOP2 with abs needs VOP3: plain VOP2 max
+            asm volatile(
+                "v_max_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_max_f32 %3, %3, %8\n"
+                "v_max_f32 %4, %4, %8\n v_max_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_max_f32 %7, %7, %8\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                : "v"(b));
+        } else if (MODE == 22) {  // v_max_f32 e64 with |abs| on both
+            asm volatile(
+                "v_max_f32_e64 %0, |%0|, |%8|\n v_max_f32_e64 %1, |%1|, |%8|\n v_max_f32_e64 %2, |%2|, |%8|\n v_max_f32_e64 %3, |%3|, |%8|\n"
+                "v_max_f32_e64 %4, |%4|, |%8|\n v_max_f32_e64 %5, |%5|, |%8|\n v_max_f32_e64 %6, |%6|, |%8|\n v_max_f32_e64 %7, |%7|, |%8|\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                : "v"(b));
+        } else if (MODE == 23) {  // v_and_b32 / v_or3_b32
+            asm volatile(
+                "v_or3_b32 %0, %0, %8, %9\n v_or3_b32 %1, %1, %8, %9\n v_or3_b32 %2, %2, %8, %9\n v_or3_b32 %3, %3, %8, %9\n"
+                "v_and_b32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_and_b32 %6, %6, %8\n v_and_b32 %7, %7, %8\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                : "v"(b), "v"(a));
         }
         else if (MODE == 6) {  // SGPR in src0 of v_fma
             asm volatile(
@@ -251,12 +283,17 @@ int main()
     run_rate<10>("v_sub/v_mul sgpr src0 (VOP2)", dout, n_cu, 1);
     run_rate<11>("16 v_fma per ds_read_b128 bcast", dout, n_cu, 2);
     run_rate<12>("7 v_fma + 1 v_cmp(sgpr)", dout, n_cu, 15.0/8);
-    run_rate<13>("v_fma + v_cmp_e32 vcc + s_or", dout, n_cu, 1.5);
     run_rate<14>("v_fma + v_cmp_e64 |abs| vgpr", dout, n_cu, 1.5);
     run_rate<15>("v_max3_f32", dout, n_cu, 2);
     run_rate<16>("v_pk_mul_f32", dout, n_cu, 2);
     run_rate<17>("v_fma + v_cmp_e64 vgpr", dout, n_cu, 1.5);
     run_rate<18>("v_cmp_e64 vgpr only", dout, n_cu, 1);
+    run_rate<13>("v_cmp_e32 vcc only", dout, n_cu, 1);
+    run_rate<19>("v_cmp_e32 vcc + s_or_b64", dout, n_cu, 1);
+    run_rate<20>("v_cmp_ge_u32_e64", dout, n_cu, 1);
+    run_rate<21>("v_max_f32 VOP2", dout, n_cu, 1);
+    run_rate<22>("v_max_f32_e64 |a|,|b|", dout, n_cu, 1);
+    run_rate<23>("v_or3_b32 x4 + v_and_b32 x4", dout, n_cu, 1);
 
     // conformance
     const int n = 1 << 22;
