@@ -68,13 +68,35 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal knob for a 1-GPU box: all ranks share device 0 and the collective runs over gloo on host copies.
+    rehearsal = os.environ.get("RT_BENCH_SINGLE_DEVICE") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    def reduce_fb(t):
+        if rehearsal:
+            h = t.cpu()
+            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+
+    def allreduce_scalar(t, op):
+        if rehearsal:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
     engine.init(dev.index)
 
     cfg = synth.config_c2(args.width, args.height)
@@ -96,7 +118,7 @@ def main():
         scene.render_dev(cfg["gen"], cfg["spp"], st, seed, 0, n_cells, 1, fb.data_ptr(), first_id.data_ptr(), first_t.data_ptr(),
                          seg.data_ptr(), total.data_ptr(), stream)
         if world > 1:
-            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+            reduce_fb(fb)
 
     def barrier():
         if world > 1:
@@ -117,7 +139,7 @@ def main():
                          seg.data_ptr(), total.data_ptr(), stream)
         ev[k][1].record()
         if world > 1:
-            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+            reduce_fb(fb)
     barrier()
     elapsed = time.perf_counter() - t0
     segs_per_step = int(total.item())
@@ -126,8 +148,8 @@ def main():
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     s = torch.tensor([segs_per_step], dtype=torch.int64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        allreduce_scalar(t, dist.ReduceOp.MAX)
+        allreduce_scalar(s, dist.ReduceOp.SUM)
     elapsed_max = float(t.item())
     segs_all = int(s.item())
 
