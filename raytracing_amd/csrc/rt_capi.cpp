@@ -28,6 +28,8 @@ struct Context {
     size_t fb_q_bytes = 0;
     uint32_t* secq = nullptr;  // continuing-ray rings of the pinhole kernel (grow-only)
     size_t secq_bytes = 0;
+    float4* prim_table = nullptr;  // streamed shared-origin table (grow-only)
+    size_t prim_table_bytes = 0;
 };
 Context g_ctx;
 constexpr unsigned kCounterRing = 1024;
@@ -122,8 +124,7 @@ int g_scan_mode = 0;
 bool use_pinhole(const rt::TraceParams& p)
 {
     if (getenv("RT_HIP_NO_PINHOLE")) return false;  // tuning / A-B knob
-    return !p.rays && p.gen.kind == RT_GEN_PROJECTOR && p.scan_mode == 0 && p.sc.n_sph_pad <= (uint32_t)rt::kTileSpheres &&
-           p.fb_q != nullptr;
+    return !p.rays && p.gen.kind == RT_GEN_PROJECTOR && p.scan_mode == 0 && p.fb_q != nullptr;
 }
 
 int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream, const rt_scene* scene)
@@ -146,12 +147,23 @@ int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream,
         if (need > g_ctx.secq_bytes) {
             HIP_TRY(hipDeviceSynchronize());
             (void)hipFree(g_ctx.secq);
+        (void)hipFree(g_ctx.prim_table);
             g_ctx.secq = nullptr;
             g_ctx.secq_bytes = 0;
             HIP_TRY(hipMalloc((void**)&g_ctx.secq, need));
             g_ctx.secq_bytes = need;
         }
         p.secq = g_ctx.secq;
+        const size_t tneed = rt::pinhole_table_bytes(p);
+        if (tneed > g_ctx.prim_table_bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(g_ctx.prim_table);
+            g_ctx.prim_table = nullptr;
+            g_ctx.prim_table_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&g_ctx.prim_table, tneed));
+            g_ctx.prim_table_bytes = tneed;
+        }
+        p.prim_table = g_ctx.prim_table;
         HIP_TRY(rt::launch_pinhole(p, g_ctx.n_cu, stream));
     } else {
         HIP_TRY(rt::launch_trace(p, g_ctx.n_cu, stream));
@@ -180,6 +192,7 @@ int rt_hip_init(int device_ordinal)
         (void)hipFree(g_ctx.counters);
         (void)hipFree(g_ctx.fb_q);
         (void)hipFree(g_ctx.secq);
+        (void)hipFree(g_ctx.prim_table);
         g_ctx = Context{};
     }
     if (!g_ctx.ready) {
@@ -199,6 +212,7 @@ void rt_hip_shutdown(void)
         (void)hipFree(g_ctx.counters);
         (void)hipFree(g_ctx.fb_q);
         (void)hipFree(g_ctx.secq);
+        (void)hipFree(g_ctx.prim_table);
         g_ctx = Context{};
     }
 }
@@ -254,7 +268,9 @@ int rt_hip_scene_create(const RtObject* objects, uint64_t n_objects, rt_scene** 
         }
     }
     const uint32_t n_sph = (uint32_t)sph_cull.size();
-    const uint32_t n_pad = (n_sph + rt::kUnroll - 1) / rt::kUnroll * rt::kUnroll;
+    // LDS mode: pad to the scan step; streamed mode (above kTileSpheres): pad to whole 64-sphere wave loads
+    const uint32_t pad_to = n_sph > (uint32_t)rt::kTileSpheres ? 64u : (uint32_t)rt::kUnroll;
+    const uint32_t n_pad = (n_sph + pad_to - 1) / pad_to * pad_to;
     const float inf = std::numeric_limits<float>::infinity();
     for (uint32_t k = n_sph; k < n_pad; ++k) {
         sph_cull.push_back(make_float4(0, 0, 0, inf));  // never passes the filter

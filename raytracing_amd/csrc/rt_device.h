@@ -208,39 +208,36 @@ struct ScanConsts {
     bool live[R];
 };
 
+// One scan step: kUnroll spheres (already in registers) against every slot of the wave.
 template <int R, int FLAVOR>
-__device__ __forceinline__ void scan_tile(const float4* tile, unsigned count, unsigned jbase, const ScanConsts<R>& c,
-                                          WaveLds<R>& w, const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane)
+__device__ __forceinline__ void scan_step(const float4 (&sp)[kUnroll], unsigned jg, const ScanConsts<R>& c, WaveLds<R>& w,
+                                          const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane)
 {
-    for (unsigned j = 0; j < count; j += kUnroll) {
-        float4 sp[kUnroll];
+    unsigned long long mk[kUnroll][R];
+    unsigned long long any = 0;
+    if (FLAVOR == 1) {
+        // stage-wise so the kUnroll*R dot products are independent chains (the scan is issue-bound, not latency-bound)
+        float h[kUnroll][R];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) sp[u] = tile[j + u];
-        unsigned long long mk[kUnroll][R];
-        unsigned long long any = 0;
-        if (FLAVOR == 1) {
-            // stage-wise so the kUnroll*R dot products are independent chains (the scan is issue-bound, not latency-bound)
-            float h[kUnroll][R];
+        for (int u = 0; u < kUnroll; ++u)
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
+            for (int r = 0; r < R; ++r) h[u][r] = sp[u].z * c.dh[r].z;
 #pragma unroll
-                for (int r = 0; r < R; ++r) h[u][r] = sp[u].z * c.dh[r].z;
+        for (int u = 0; u < kUnroll; ++u)
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
+            for (int r = 0; r < R; ++r) h[u][r] = __builtin_fmaf(sp[u].y, c.dh[r].y, h[u][r]);
 #pragma unroll
-                for (int r = 0; r < R; ++r) h[u][r] = __builtin_fmaf(sp[u].y, c.dh[r].y, h[u][r]);
+        for (int u = 0; u < kUnroll; ++u)
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
+            for (int r = 0; r < R; ++r) h[u][r] = __builtin_fmaf(sp[u].x, c.dh[r].x, h[u][r]);
 #pragma unroll
-                for (int r = 0; r < R; ++r) h[u][r] = __builtin_fmaf(sp[u].x, c.dh[r].x, h[u][r]);
+        for (int u = 0; u < kUnroll; ++u)
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    mk[u][r] = __ballot(__builtin_fabsf(h[u][r]) >= sp[u].w);
-                    any |= mk[u][r];
-                }
-        } else {
+            for (int r = 0; r < R; ++r) {
+                mk[u][r] = __ballot(__builtin_fabsf(h[u][r]) >= sp[u].w);
+                any |= mk[u][r];
+            }
+    } else {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
 #pragma unroll
@@ -252,26 +249,61 @@ __device__ __forceinline__ void scan_tile(const float4* tile, unsigned count, un
                     float q = __builtin_fmaf(h, h, -S);
                     pass = q >= sp[u].w;
                 } else {
-                    float4 se = sc.sph_exact[jbase + j + u];
+                    float4 se = sc.sph_exact[jg + u];
                     F3 lo = c.o[r] - f3(se.x, se.y, se.z);
                     float half_b = dot(lo, c.d[r]);
                     float cc = dot(lo, lo) - se.w * se.w;
                     float disc = half_b * half_b - c.a[r] * cc;
-                    pass = c.live[r] && (jbase + j + u < sc.n_sph) && !(disc < 0.0f);
+                    pass = c.live[r] && (jg + u < sc.n_sph) && !(disc < 0.0f);
                 }
                 mk[u][r] = __ballot(pass);
                 any |= mk[u][r];
             }
         }
-        }
-        if (any) {
+    }
+    if (any) {
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < kUnroll; ++u) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (mk[u][r]) push_candidates<R>(w, sc, mk[u][r], r * 64, jbase + j + u, head, tail, lane);
-                }
+            for (int r = 0; r < R; ++r) {
+                if (mk[u][r]) push_candidates<R>(w, sc, mk[u][r], r * 64, jg + u, head, tail, lane);
             }
+        }
+    }
+}
+
+// The scan over a whole sphere table.
+//   PF = false: `tile` is the block's LDS table; every step reads kUnroll spheres with wave-uniform ds_read_b128.
+//   PF = true : the table (count % 64 == 0) lives in global memory / L2 (scenes above kTileSpheres).  A wave-uniform
+//               vector load would cost a full 1 KiB TA pass per 16 bytes, so instead each lane fetches ONE sphere
+//               (64 spheres per coalesced load), the wave parks them in its own 2 x 1 KiB LDS staging buffer and then
+//               broadcasts them exactly like the LDS mode; the next 64 are in flight while the current 64 are tested.
+template <int R, int FLAVOR, bool PF>
+__device__ __forceinline__ void scan_tile(const float4* tile, unsigned count, float4* stage, const ScanConsts<R>& c,
+                                          WaveLds<R>& w, const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane)
+{
+    if (!PF) {
+        for (unsigned j = 0; j < count; j += kUnroll) {
+            float4 sp[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) sp[u] = tile[j + u];
+            scan_step<R, FLAVOR>(sp, j, c, w, sc, head, tail, lane);
+        }
+    } else {
+        if (count == 0) return;
+        float4 nxt = tile[lane];
+        unsigned buf = 0;
+        for (unsigned base = 0; base < count; base += 64) {
+            stage[buf * 64 + lane] = nxt;
+            if (base + 64 < count) nxt = tile[base + 64 + lane];
+            wave_lds_sync();
+            for (unsigned j = 0; j < 64; j += kUnroll) {
+                float4 sp[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) sp[u] = stage[buf * 64 + j + u];
+                scan_step<R, FLAVOR>(sp, base + j, c, w, sc, head, tail, lane);
+            }
+            buf ^= 1;
         }
     }
 }

@@ -7,7 +7,7 @@
 
 namespace rt {
 
-constexpr int kTileSpheres = 1024;  // spheres per LDS tile (16 KiB of float4): 4 blocks (16 waves) per CU
+constexpr int kTileSpheres = 1024;  // largest sphere table staged in LDS (16 KiB of float4); larger scenes are streamed from L2
 constexpr int kBlockThreads = 256;  // 4 waves
 constexpr uint32_t kUnitSamples = 8;  // samples of one cell traced back to back by one lane (render work unit)
 constexpr int kUnroll = 4;          // spheres per scan step; sphere arrays are padded to a multiple
@@ -61,6 +61,7 @@ struct TraceParams {
     // pinhole kernel only
     uint32_t* secq;     // per-wave rings of continuing rays: [grid waves][kSecFields][kSecCap] dwords
     float prim_margin;  // >= 64 u * max_j(|p_j - O|^2 + r_j^2): margin of the shared-origin filter
+    float4* prim_table; // streamed mode only: [n_sph_pad] {p - O, sK}, rebuilt per launch
 };
 
 constexpr unsigned kSecCap = 256;    // entries per wave ring (a primary step adds <= 128 to a residue < 128)
@@ -68,9 +69,10 @@ constexpr unsigned kSecFields = 10;  // o.xyz d.xyz ior cell sample bounce
 
 // Launches the trace kernel on `stream`; d_work = {unsigned long long total_segments; unsigned next_cell} scratch.
 hipError_t launch_trace(const TraceParams& p, int n_cu, hipStream_t stream);
-// Shared-origin (Projector) specialisation; needs n_sph_pad <= kTileSpheres. secq must hold pinhole_secq_bytes().
+// Shared-origin (Projector) specialisation. secq must hold pinhole_secq_bytes(), prim_table pinhole_table_bytes().
 hipError_t launch_pinhole(const TraceParams& p, int n_cu, hipStream_t stream);
 size_t pinhole_secq_bytes(const TraceParams& p, int n_cu);
+size_t pinhole_table_bytes(const TraceParams& p);
 hipError_t launch_finalize(const unsigned long long* fb_q, float* fb, uint64_t n_values, uint32_t spp, hipStream_t stream);
 
 }  // namespace rt

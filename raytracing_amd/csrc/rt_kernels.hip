@@ -29,20 +29,23 @@ namespace rt {
 
 namespace {
 
-template <int R, int MODE>
+// STREAM = false: the sphere table (<= kTileSpheres) is staged in LDS once per block.
+// STREAM = true : larger scenes; every wave streams the table from global memory / L2 (scan_tile<.., PF = true>).
+// Waves never synchronise with each other after the table is staged.
+template <int R, int MODE, bool STREAM>
 __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams p)
 {
-    __shared__ float4 tile[kTileSpheres];
+    __shared__ float4 tile[STREAM ? 1 : kTileSpheres];
     __shared__ WaveLds<R> wl[kBlockThreads / 64];
+    __shared__ float4 stage_all[STREAM ? (kBlockThreads / 64) * 128 : 1];
 
     const unsigned lane = lane_id();
     const unsigned wave = threadIdx.x >> 6;
     WaveLds<R>& w = wl[wave];
+    float4* stage = stage_all + (STREAM ? wave * 128 : 0);
     const DevScene& sc = p.sc;
-    const unsigned n_tiles = (sc.n_sph_pad + kTileSpheres - 1) / kTileSpheres;
-    const bool multi = n_tiles > 1;
 
-    if (!multi) {
+    if (!STREAM) {
         for (unsigned k = threadIdx.x; k < sc.n_sph_pad; k += kBlockThreads) tile[k] = sc.sph_cull[k];
         __syncthreads();
     }
@@ -119,11 +122,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             }
             if (!any_live) wave_done = true;
         }
-        if (multi) {
-            if (__syncthreads_and(wave_done ? 1 : 0)) break;
-        } else if (wave_done) {
-            break;
-        }
+        if (wave_done) break;
 
         // ---- 2. per-segment constants ----
         ScanConsts<R> c;
@@ -149,18 +148,10 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
         wave_lds_sync();
 
         // ---- 3. scan the sphere list ----
-        for (unsigned t_i = 0; t_i < n_tiles; ++t_i) {
-            unsigned count = sc.n_sph_pad - t_i * kTileSpheres;
-            if (count > (unsigned)kTileSpheres) count = kTileSpheres;
-            if (multi) {
-                __syncthreads();
-                for (unsigned k = threadIdx.x; k < count; k += kBlockThreads) tile[k] = sc.sph_cull[t_i * kTileSpheres + k];
-                __syncthreads();
-                if (wave_done) continue;
-            }
-            scan_tile<R, (MODE == 0 ? 0 : 2)>(tile, count, t_i * kTileSpheres, c, w, sc, head, tail, lane);
-        }
-        if (wave_done) continue;  // multi-tile mode: this wave only keeps the barriers company
+        if (STREAM)
+            scan_tile<R, (MODE == 0 ? 0 : 2), true>(sc.sph_cull, sc.n_sph_pad, stage, c, w, sc, head, tail, lane);
+        else
+            scan_tile<R, (MODE == 0 ? 0 : 2), false>(tile, sc.n_sph_pad, stage, c, w, sc, head, tail, lane);
 
         // ---- 4. drain the queue ----
         wave_lds_sync();
@@ -322,23 +313,27 @@ static int blocks_per_cu(K kernel)
     return n;
 }
 
-hipError_t launch_trace(const TraceParams& p, int n_cu, hipStream_t stream)
+template <int MODE, bool STREAM>
+static hipError_t launch_trace_t(const TraceParams& p, int n_cu, hipStream_t stream)
 {
     constexpr int R = 2;
-    static const int occ0 = blocks_per_cu(trace_kernel<R, 0>);
-    static const int occ1 = blocks_per_cu(trace_kernel<R, 1>);
-    // persistent grid: exactly the resident capacity (every block pulls cells until the counter runs out),
+    static const int occ = blocks_per_cu(trace_kernel<R, MODE, STREAM>);
+    // persistent grid: exactly the resident capacity (every block pulls units until the counter runs out),
     // never more blocks than the work can feed
     const uint64_t slots_per_block = (uint64_t)kBlockThreads * R;
     const uint64_t want = ((uint64_t)p.cell_count * p.units_per_cell + slots_per_block - 1) / slots_per_block;
-    const uint64_t cap = (uint64_t)n_cu * (p.scan_mode == 0 ? occ0 : occ1);
+    const uint64_t cap = (uint64_t)n_cu * occ;
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     if (blocks == 0) blocks = 1;
-    if (p.scan_mode == 0)
-        hipLaunchKernelGGL((trace_kernel<R, 0>), dim3(blocks), dim3(kBlockThreads), 0, stream, p);
-    else
-        hipLaunchKernelGGL((trace_kernel<R, 1>), dim3(blocks), dim3(kBlockThreads), 0, stream, p);
+    hipLaunchKernelGGL((trace_kernel<R, MODE, STREAM>), dim3(blocks), dim3(kBlockThreads), 0, stream, p);
     return hipGetLastError();
+}
+
+hipError_t launch_trace(const TraceParams& p, int n_cu, hipStream_t stream)
+{
+    const bool stream_table = p.sc.n_sph_pad > (uint32_t)kTileSpheres;
+    if (p.scan_mode == 0) return stream_table ? launch_trace_t<0, true>(p, n_cu, stream) : launch_trace_t<0, false>(p, n_cu, stream);
+    return stream_table ? launch_trace_t<1, true>(p, n_cu, stream) : launch_trace_t<1, false>(p, n_cu, stream);
 }
 
 hipError_t launch_finalize(const unsigned long long* fb_q, float* fb, uint64_t n_values, uint32_t spp, hipStream_t stream)

@@ -18,39 +18,52 @@ namespace {
 
 constexpr int kPinThreads = 512;  // 8 waves share the two LDS tables; 2 blocks per CU = 4 waves per SIMD
 
-template <int R>
+// One entry of the shared-origin table: {p - O, sK}.
+__device__ __forceinline__ float4 pinhole_entry(const DevScene& sc, unsigned k, F3 O, float prim_margin)
+{
+    if (k >= sc.n_sph) return make_float4(0.f, 0.f, 0.f, __builtin_inff());  // padding never passes
+    const float4 e = sc.sph_exact[k];
+    // p' = fl(p - O) is exactly minus the reference's local origin fl(O - p) (transform.rs:22), so K' below is
+    // exact for the operands every later test uses.
+    const float px = e.x - O.x, py = e.y - O.y, pz = e.z - O.z;
+    const double K = ((double)px * px + (double)py * py + (double)pz * pz) - (double)e.w * e.w;
+    const double Kq = K - (double)prim_margin;
+    const float sK = (Kq <= 0.0) ? -1.0f : (float)(__builtin_sqrt(Kq) * (1.0 - 0x1p-22));
+    return make_float4(px, py, pz, sK);
+}
+
+// Streamed variant: the table is built once per launch in global memory.
+__global__ void pinhole_table_kernel(const TraceParams p, float4* table)
+{
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < p.sc.n_sph_pad) table[k] = pinhole_entry(p.sc, k, f3(p.gen.a[0], p.gen.a[1], p.gen.a[2]), p.prim_margin);
+}
+
+// STREAM = false: both tables (<= kTileSpheres spheres) live in LDS.  STREAM = true: both are streamed from global / L2.
+template <int R, bool STREAM>
 __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TraceParams p)
 {
-    extern __shared__ float4 tiles[];  // [n_sph_pad] general {p, K}  then  [n_sph_pad] pinhole {p - O, sK}
+    extern __shared__ float4 tiles[];  // [n_sph_pad] general {p, K}  then  [n_sph_pad] pinhole {p - O, sK}  (LDS mode)
     __shared__ WaveLds<R> wl[kPinThreads / 64];
+    __shared__ float4 stage_all[STREAM ? (kPinThreads / 64) * 128 : 1];
 
     const unsigned lane = lane_id();
     const unsigned wave = threadIdx.x >> 6;
     WaveLds<R>& w = wl[wave];
+    float4* stage = stage_all + (STREAM ? wave * 128 : 0);
     const DevScene& sc = p.sc;
     const unsigned n_pad = sc.n_sph_pad;
-    float4* tileG = tiles;
-    float4* tileP = tiles + n_pad;
     const F3 O = f3(p.gen.a[0], p.gen.a[1], p.gen.a[2]);
+    const float4* tileG = STREAM ? sc.sph_cull : tiles;
+    const float4* tileP = STREAM ? p.prim_table : tiles + n_pad;
 
-    for (unsigned k = threadIdx.x; k < n_pad; k += kPinThreads) {
-        tileG[k] = sc.sph_cull[k];
-        float4 e = sc.sph_exact[k];
-        float4 t4;
-        if (k < sc.n_sph) {
-            // p' = fl(p - O) is exactly minus the reference's local origin fl(O - p) (transform.rs:22), so K' below is
-            // exact for the operands every later test uses.
-            const float px = e.x - O.x, py = e.y - O.y, pz = e.z - O.z;
-            const double K = ((double)px * px + (double)py * py + (double)pz * pz) - (double)e.w * e.w;
-            const double Kq = K - (double)p.prim_margin;
-            const float sK = (Kq <= 0.0) ? -1.0f : (float)(__builtin_sqrt(Kq) * (1.0 - 0x1p-22));
-            t4 = make_float4(px, py, pz, sK);
-        } else {
-            t4 = make_float4(0.f, 0.f, 0.f, __builtin_inff());
+    if (!STREAM) {
+        for (unsigned k = threadIdx.x; k < n_pad; k += kPinThreads) {
+            tiles[k] = sc.sph_cull[k];
+            tiles[n_pad + k] = pinhole_entry(sc, k, O, p.prim_margin);
         }
-        tileP[k] = t4;
+        __syncthreads();
     }
-    __syncthreads();
 
     // per-wave ring of continuing rays (global memory, only this wave touches it)
     const unsigned gwave = blockIdx.x * (kPinThreads / 64) + wave;
@@ -137,7 +150,7 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 c.dh[r] = live[r] ? rd[r] * rs : f3(nanv, nanv, nanv);  // NaN never passes |h| >= sK
             }
             wave_lds_sync();
-            scan_tile<R, 1>(tileP, n_pad, 0, c, w, sc, head, tail, lane);
+            scan_tile<R, 1, STREAM>(tileP, n_pad, stage, c, w, sc, head, tail, lane);
         } else {
             // ================= continuing-ray step =================
             const unsigned n_pop = sec_count < 64u * R ? sec_count : 64u * R;
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 c.pp[r] = f3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z);
             }
             wave_lds_sync();
-            scan_tile<R, 0>(tileG, n_pad, 0, c, w, sc, head, tail, lane);
+            scan_tile<R, 0, STREAM>(tileG, n_pad, stage, c, w, sc, head, tail, lane);
         }
 
         // ---- drain the candidate queue, resolve ----
@@ -270,10 +283,14 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
 
 constexpr int kR = 2;
 
+inline bool stream_mode(const TraceParams& p) { return p.sc.n_sph_pad > (uint32_t)kTileSpheres; }
+inline size_t dyn_lds(const TraceParams& p) { return stream_mode(p) ? 0 : (size_t)p.sc.n_sph_pad * sizeof(float4) * 2; }
+
+template <bool STREAM>
 int pinhole_blocks_per_cu(size_t dyn_bytes)
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pinhole_kernel<kR>, kPinThreads, dyn_bytes) != hipSuccess || n < 1) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pinhole_kernel<kR, STREAM>, kPinThreads, dyn_bytes) != hipSuccess || n < 1) n = 1;
     if (const char* e = getenv("RT_HIP_BLOCKS_PER_CU")) {  // tuning knob
         int v = atoi(e);
         if (v >= 1 && v <= 8) n = v;
@@ -283,10 +300,10 @@ int pinhole_blocks_per_cu(size_t dyn_bytes)
 
 unsigned pinhole_grid(const TraceParams& p, int n_cu)
 {
-    const size_t dyn = (size_t)p.sc.n_sph_pad * sizeof(float4) * 2;
+    const size_t dyn = dyn_lds(p);
     const uint64_t slots_per_block = (uint64_t)kPinThreads * kR;
     const uint64_t want = ((uint64_t)p.cell_count * p.units_per_cell + slots_per_block - 1) / slots_per_block;
-    const uint64_t cap = (uint64_t)n_cu * pinhole_blocks_per_cu(dyn);
+    const uint64_t cap = (uint64_t)n_cu * (stream_mode(p) ? pinhole_blocks_per_cu<true>(dyn) : pinhole_blocks_per_cu<false>(dyn));
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     return blocks ? blocks : 1;
 }
@@ -298,17 +315,26 @@ size_t pinhole_secq_bytes(const TraceParams& p, int n_cu)
     return (size_t)pinhole_grid(p, n_cu) * (kPinThreads / 64) * kSecFields * kSecCap * sizeof(uint32_t);
 }
 
+size_t pinhole_table_bytes(const TraceParams& p) { return stream_mode(p) ? (size_t)p.sc.n_sph_pad * sizeof(float4) : 0; }
+
 hipError_t launch_pinhole(const TraceParams& p, int n_cu, hipStream_t stream)
 {
-    const size_t dyn = (size_t)p.sc.n_sph_pad * sizeof(float4) * 2;
+    const unsigned grid = pinhole_grid(p, n_cu);
+    if (stream_mode(p)) {
+        hipLaunchKernelGGL(pinhole_table_kernel, dim3((p.sc.n_sph_pad + 255) / 256), dim3(256), 0, stream, p, p.prim_table);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((pinhole_kernel<kR, true>), dim3(grid), dim3(kPinThreads), 0, stream, p);
+        return hipGetLastError();
+    }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)pinhole_kernel<kR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)pinhole_kernel<kR, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(kTileSpheres * sizeof(float4) * 2));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((pinhole_kernel<kR>), dim3(pinhole_grid(p, n_cu)), dim3(kPinThreads), dyn, stream, p);
+    hipLaunchKernelGGL((pinhole_kernel<kR, false>), dim3(grid), dim3(kPinThreads), dyn_lds(p), stream, p);
     return hipGetLastError();
 }
 

@@ -263,3 +263,23 @@ def test_grazing_rays_stress_filter(engine):
     (pts, npts, recs), (opts, onpts, orecs) = _simulate_both(engine, objs, rays, 50.0, 4)
     assert np.array_equal(npts, onpts)
     assert_records_equal(recs, orecs, "grazing")
+
+
+@pytest.mark.parametrize("n_spheres", [1025, 3000])
+def test_render_parity_streamed_table(engine, n_spheres):
+    """Scenes above the LDS tile size (1,024 spheres): both kernels stream the sphere table from L2 instead."""
+    objs = random_scene(n_spheres, 2, seed=n_spheres, extent=(60.0, 30.0, 60.0))
+    gen = projector((0.0, 0.0, -150.0), (-70.0, -40.0, -70.0), (140.0, 0.0, 0.0), (0.0, 80.0, 0.0), 48, 32)
+    st = SimulationSettingsConfig(60.0, 6)
+    sc = engine.Scene(objs)
+    got = sc.render(gen, 3, st, seed=9)
+    want = ob.OracleScene(objs).render(gen, 3, 60.0, 6, seed=9, threads=8)
+    for a, b in zip(got[:4], want[:4]):
+        assert np.array_equal(a, b)
+    assert got[4] == want[4]
+    # general kernel (ParallelGrid) on the same scene
+    gen2 = parallel_grid((-60, -30, -100), (120, 0, 0), (0, 60, 0), 40, 24, (0.02, 0.01, 1.0))
+    got = sc.render(gen2, 2, st, seed=9)
+    want = ob.OracleScene(objs).render(gen2, 2, 60.0, 6, seed=9, threads=8)
+    for a, b in zip(got[:4], want[:4]):
+        assert np.array_equal(a, b)
