@@ -147,7 +147,6 @@ int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream,
         if (need > g_ctx.secq_bytes) {
             HIP_TRY(hipDeviceSynchronize());
             (void)hipFree(g_ctx.secq);
-        (void)hipFree(g_ctx.prim_table);
             g_ctx.secq = nullptr;
             g_ctx.secq_bytes = 0;
             HIP_TRY(hipMalloc((void**)&g_ctx.secq, need));
