@@ -41,6 +41,19 @@ extern "C" {
 /* ---- ShapeConfig arms on the GPU path (crates/raytracing_config/src/model/shape_config.rs:56-60, 69-73) ---- */
 #define RT_SHAPE_SPHERE 0u /* shape_param[0] = radius; local centre is the origin */
 #define RT_SHAPE_PLANE 1u  /* shape_param[0..2] = normal (NOT normalised, as in the reference); local point is the origin */
+/* The remaining ShapeConfig arms (shape_config.rs:61-68, 74-149).  They, and any object with rotation_y_deg != 0, take the
+ * per-lane "complex object" path of the kernels (exact intersect_all + CSG state machine, csg.rs:9-75). */
+#define RT_SHAPE_BOX 2u      /* shape_param[0..2] = size                        -> AxisAlignedBox(-size/2, size/2) */
+#define RT_SHAPE_CYLINDER 3u /* shape_param[0] = height, [1] = radius           -> (InfiniteCylinder & cap) & cap  */
+#define RT_SHAPE_CONE 4u     /* shape_param[0] = angle_deg, [1] = height        -> InfiniteCone & cap              */
+#define RT_SHAPE_WEDGE 5u    /* shape_param[0..2] = size, [3] = angle_deg       -> five planes intersected         */
+#define RT_SHAPE_LENS 6u     /* thickness, diameter, r1, r2                     -> (surface & surface) & cylinder  */
+#define RT_SHAPE_TREE 7u     /* Union/Intersection/Difference tree; the bits of shape_param[0] are the uint32 index of
+                                the root RtShapeNode (rt_hip_scene_create_ex) */
+/* operator codes, RtShapeNode only (shape_config.rs:39-50) */
+#define RT_SHAPE_UNION 16u
+#define RT_SHAPE_INTERSECTION 17u
+#define RT_SHAPE_DIFFERENCE 18u
 
 /* One ObjectConfig after generator expansion (object_config.rs:10-14, transform_config.rs:3-7).
  * The reference wraps every such object in Transform(T(position) * R_y(rotation_y_deg))
@@ -49,10 +62,20 @@ typedef struct RtObject {
     uint32_t shape;          /* RT_SHAPE_* */
     uint32_t material_kind;  /* RT_MAT_* */
     float material_param;    /* ior | reflectance | unused */
-    float rotation_y_deg;    /* must be 0 on the GPU path this round (RT_ERR_UNSUPPORTED otherwise) */
+    float rotation_y_deg;    /* any value; 0 keeps spheres and planes on the fast scan path */
     float position[3];
     float shape_param[4];
 } RtObject; /* 44 bytes */
+
+/* One node of a Union/Intersection/Difference ShapeConfig tree (shape_config.rs:39-50): a leaf is any of
+ * RT_SHAPE_SPHERE..RT_SHAPE_LENS with its shape_param (no transform: only the whole object is wrapped in a
+ * Transform), an operator is RT_SHAPE_UNION/INTERSECTION/DIFFERENCE with child node indices a and b. */
+typedef struct RtShapeNode {
+    uint32_t shape;
+    uint32_t a;
+    uint32_t b;
+    float shape_param[4];
+} RtShapeNode; /* 28 bytes */
 
 /* Ray (scene.rs:110-115), 28 bytes. Direction is used as given (the reference normalises when it
  * builds rays from config: ray_config.rs:16, scene_config.rs:72,103). */
@@ -109,6 +132,9 @@ const char* rt_hip_last_error(void);
 /* Flatten and upload the object list: the GPU-side counterpart of building `Scene.objects`
  * (scene_config.rs:25-52 + object_config.rs:16-30 + transform.rs:11-17). */
 int rt_hip_scene_create(const RtObject* objects, uint64_t n_objects, rt_scene** out_scene);
+/* Same, with the node array that RT_SHAPE_TREE objects index (nodes may be NULL when n_nodes == 0). */
+int rt_hip_scene_create_ex(const RtObject* objects, uint64_t n_objects, const RtShapeNode* nodes, uint64_t n_nodes,
+                           rt_scene** out_scene);
 void rt_hip_scene_destroy(rt_scene* scene);
 
 /* ---- the hot call: Scene::simulate_rays (scene.rs:39-106) ----

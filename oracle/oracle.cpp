@@ -18,11 +18,13 @@
 // (SURVEY §8 a14); it restates DESIGN.md's definition and is the only check for it.
 #include "../include/rt_hip.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -188,6 +190,290 @@ inline bool plane_first_hit(V3 ppoint, V3 normal, const Ray& ray, float t_min, f
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Generic `Hittable::intersect_all` (primitives/mod.rs:46-48) for the shapes that are not on the fast
+// sphere/plane path: every hit in (t_min, t_max), in the order the reference pushes them.
+// ---------------------------------------------------------------------------------------------------
+struct Prim {
+    virtual ~Prim() {}
+    virtual void intersect_all(const Ray& ray, float t_min, float t_max, std::vector<Hit>& out) const = 0;
+};
+
+struct SpherePrim : Prim {  // sphere.rs:12-74
+    V3 center;
+    float radius;
+    void intersect_all(const Ray& ray, float t_min, float t_max, std::vector<Hit>& out) const override
+    {
+        V3 oc = ray.origin - center;
+        float a = length_squared(ray.direction);
+        float half_b = dot(oc, ray.direction);
+        float c = length_squared(oc) - radius * radius;
+        float discriminant = half_b * half_b - a * c;
+        if (discriminant < 0.0f) return;
+        float sqrtd = std::sqrt(discriminant);
+        auto push = [&](float t) {
+            V3 point = ray.origin + t * ray.direction;
+            V3 outward = (point - center) / radius;
+            bool front = dot(ray.direction, outward) < 0.0f;
+            Hit h{};
+            h.t = t; h.point = point; h.normal = front ? outward : -outward; h.front_face = front;
+            out.push_back(h);
+        };
+        float t1 = (-half_b - sqrtd) / a;
+        if (t1 > t_min && t1 < t_max) push(t1);
+        if (discriminant > 1e-6f) {
+            float t2 = (-half_b + sqrtd) / a;
+            if (t2 > t_min && t2 < t_max) push(t2);
+        }
+    }
+};
+
+struct PlanePrim : Prim {  // plane.rs:12-54
+    V3 point, normal;
+    void intersect_all(const Ray& ray, float t_min, float t_max, std::vector<Hit>& out) const override
+    {
+        Hit h{};
+        if (plane_first_hit(point, normal, ray, t_min, t_max, h)) out.push_back(h);
+    }
+};
+
+struct BoxPrim : Prim {  // axis_aligned_box.rs:12-95
+    V3 mn, mx;
+    static float comp(V3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+    V3 calculate_normal(V3 point) const
+    {
+        const float epsilon = 1e-4f;
+        V3 a = point - mn, b = point - mx;
+        if (std::fabs(a.x) < epsilon) return v3(-1, 0, 0);
+        if (std::fabs(b.x) < epsilon) return v3(1, 0, 0);
+        if (std::fabs(a.y) < epsilon) return v3(0, -1, 0);
+        if (std::fabs(b.y) < epsilon) return v3(0, 1, 0);
+        if (std::fabs(a.z) < epsilon) return v3(0, 0, -1);
+        if (std::fabs(b.z) < epsilon) return v3(0, 0, 1);
+        return v3(0, 0, 0);
+    }
+    void intersect_all(const Ray& ray, float t_min, float t_max, std::vector<Hit>& out) const override
+    {
+        float tmin = t_min, tmax = t_max;
+        for (int i = 0; i < 3; ++i) {
+            float inv_d = 1.0f / comp(ray.direction, i);
+            float t0 = (comp(mn, i) - comp(ray.origin, i)) * inv_d;
+            float t1 = (comp(mx, i) - comp(ray.origin, i)) * inv_d;
+            if (inv_d < 0.0f) std::swap(t0, t1);
+            tmin = std::fmax(tmin, t0);  // f32::max: NaN-ignoring
+            tmax = std::fmin(tmax, t1);
+            if (tmax <= tmin) return;
+        }
+        Hit h1{}, h2{};
+        h1.t = tmin;
+        h1.point = ray.origin + tmin * ray.direction;
+        h1.normal = calculate_normal(h1.point);
+        h1.front_face = dot(ray.direction, h1.normal) < 0.0f;
+        out.push_back(h1);
+        h2.t = tmax;
+        h2.point = ray.origin + tmax * ray.direction;
+        h2.normal = -calculate_normal(h2.point);
+        h2.front_face = dot(ray.direction, h2.normal) < 0.0f;
+        out.push_back(h2);
+    }
+};
+
+struct InfCylinderPrim : Prim {  // infinite_cylinder.rs:13-84
+    V3 axis_point, axis_dir;
+    float radius;
+    void intersect_all(const Ray& ray, float t_min, float t_max, std::vector<Hit>& out) const override
+    {
+        V3 oc = ray.origin - axis_point;
+        float d_dot_v = dot(ray.direction, axis_dir);
+        V3 d_perp = ray.direction - d_dot_v * axis_dir;
+        float oc_dot_v = dot(oc, axis_dir);
+        V3 oc_perp = oc - oc_dot_v * axis_dir;
+        float a = length_squared(d_perp);
+        float b = 2.0f * dot(oc_perp, d_perp);
+        float c = length_squared(oc_perp) - radius * radius;
+        if (std::fabs(a) < 1e-6f) return;
+        float discriminant = b * b - 4.0f * a * c;
+        if (discriminant < 0.0f) return;
+        float sqrtd = std::sqrt(discriminant);
+        float ts[2] = {(-b - sqrtd) / (2.0f * a), (-b + sqrtd) / (2.0f * a)};
+        for (float t : ts) {
+            if (t > t_min && t < t_max) {
+                V3 point = ray.origin + t * ray.direction;
+                V3 p_minus_a = point - axis_point;
+                float projection = dot(p_minus_a, axis_dir);
+                V3 point_on_axis = axis_point + projection * axis_dir;
+                V3 outward = normalize(point - point_on_axis);
+                bool front = dot(ray.direction, outward) < 0.0f;
+                Hit h{};
+                h.t = t; h.point = point; h.normal = front ? outward : -outward; h.front_face = front;
+                out.push_back(h);
+            }
+        }
+    }
+};
+
+struct InfConePrim : Prim {  // infinite_cone.rs:14-86
+    V3 vertex, axis_dir;
+    float cos_angle_sq;
+    void intersect_all(const Ray& ray, float t_min, float t_max, std::vector<Hit>& out) const override
+    {
+        V3 co = ray.origin - vertex;
+        float d_dot_v = dot(ray.direction, axis_dir);
+        float co_dot_v = dot(co, axis_dir);
+        float a = d_dot_v * d_dot_v - cos_angle_sq;  // powi(2)
+        float b = 2.0f * (d_dot_v * co_dot_v - dot(ray.direction, co) * cos_angle_sq);
+        float c = co_dot_v * co_dot_v - length_squared(co) * cos_angle_sq;
+        float discriminant = b * b - 4.0f * a * c;
+        if (discriminant < 0.0f) return;
+        float sqrtd = std::sqrt(discriminant);
+        float ts[2] = {(-b - sqrtd) / (2.0f * a), (-b + sqrtd) / (2.0f * a)};
+        for (float t : ts) {
+            if (t > t_min && t < t_max) {
+                V3 point = ray.origin + t * ray.direction;
+                V3 pv = point - vertex;
+                float m = dot(pv, axis_dir);
+                V3 outward = normalize(m * axis_dir - pv * cos_angle_sq);
+                bool front = dot(ray.direction, outward) < 0.0f;
+                Hit h{};
+                h.t = t; h.point = point; h.normal = front ? outward : -outward; h.front_face = front;
+                out.push_back(h);
+            }
+        }
+    }
+};
+
+struct CsgPrim : Prim {  // csg.rs:3-76
+    std::unique_ptr<Prim> left, right;
+    uint32_t op;  // RT_SHAPE_UNION / INTERSECTION / DIFFERENCE
+    bool inside(bool l, bool r) const { return op == RT_SHAPE_UNION ? (l || r) : (op == RT_SHAPE_INTERSECTION ? (l && r) : (l && !r)); }
+    void intersect_all(const Ray& ray, float t_min, float t_max, std::vector<Hit>& out) const override
+    {
+        std::vector<Hit> hl, hr;
+        left->intersect_all(ray, t_min, t_max, hl);
+        right->intersect_all(ray, t_min, t_max, hr);
+        std::vector<Hit> all = hl;
+        all.insert(all.end(), hr.begin(), hr.end());
+        std::stable_sort(all.begin(), all.end(), [](const Hit& x, const Hit& y) { return x.t < y.t; });
+        bool in_left = false, in_right = false;
+        for (const Hit& hit : all) {
+            bool on_left = false;
+            for (const Hit& h : hl) on_left = on_left || (std::fabs(h.t - hit.t) < 1e-6f);
+            bool was = inside(in_left, in_right);
+            if (on_left) in_left = !in_left; else in_right = !in_right;
+            bool is = inside(in_left, in_right);
+            if (was != is) {
+                Hit h = hit;
+                if (op == RT_SHAPE_DIFFERENCE && !on_left) {
+                    h.normal = -hit.normal;
+                    h.front_face = !hit.front_face;
+                }
+                out.push_back(h);
+            }
+        }
+    }
+};
+
+inline std::unique_ptr<Prim> mk_plane(V3 point, V3 normal)
+{
+    auto p = std::make_unique<PlanePrim>();
+    p->point = point; p->normal = normal;
+    return p;
+}
+inline std::unique_ptr<Prim> mk_csg(std::unique_ptr<Prim> l, std::unique_ptr<Prim> r, uint32_t op)
+{
+    auto c = std::make_unique<CsgPrim>();
+    c->left = std::move(l); c->right = std::move(r); c->op = op;
+    return c;
+}
+const float kRadsPerDeg = 3.14159265358979323846f / 180.0f;  // f32::to_radians multiplies by PI/180 (f32 constant)
+
+// ShapeConfig::into_with (shape_config.rs:53-149), wedge.rs:10-78, lens.rs:11-76.
+std::unique_ptr<Prim> build_shape(uint32_t shape, const float* sp, const RtShapeNode* nodes, uint64_t n_nodes, int depth)
+{
+    switch (shape) {
+        case RT_SHAPE_SPHERE: {
+            auto s = std::make_unique<SpherePrim>();
+            s->center = v3(0, 0, 0); s->radius = sp[0];
+            return s;
+        }
+        case RT_SHAPE_PLANE: return mk_plane(v3(0, 0, 0), v3(sp[0], sp[1], sp[2]));
+        case RT_SHAPE_BOX: {
+            V3 h = v3(sp[0], sp[1], sp[2]) / 2.0f;
+            auto b = std::make_unique<BoxPrim>();
+            b->mn = -h; b->mx = h;
+            return b;
+        }
+        case RT_SHAPE_CYLINDER: {
+            float half_height = sp[0] / 2.0f;
+            auto body = std::make_unique<InfCylinderPrim>();
+            body->axis_point = v3(0, 0, 0); body->axis_dir = v3(0, 1, 0); body->radius = sp[1];
+            auto capped = mk_csg(std::move(body), mk_plane(v3(0, half_height, 0), v3(0, -1, 0)), RT_SHAPE_INTERSECTION);
+            return mk_csg(std::move(capped), mk_plane(v3(0, -half_height, 0), v3(0, 1, 0)), RT_SHAPE_INTERSECTION);
+        }
+        case RT_SHAPE_CONE: {
+            auto cone = std::make_unique<InfConePrim>();
+            cone->vertex = v3(0, 0, 0);
+            cone->axis_dir = normalize(v3(0, 1, 0));
+            float cs = std::cos(sp[0] * kRadsPerDeg);
+            cone->cos_angle_sq = cs * cs;
+            return mk_csg(std::move(cone), mk_plane(v3(0, sp[1], 0), v3(0, -1, 0)), RT_SHAPE_INTERSECTION);
+        }
+        case RT_SHAPE_WEDGE: {
+            float half_depth = sp[2] / 2.0f;
+            float ang = sp[3] * kRadsPerDeg;
+            float angle_cos = std::cos(ang), angle_sin = std::sin(ang);
+            auto c1 = mk_csg(mk_plane(v3(0, 0, 0), v3(0, 1, 0)), mk_plane(v3(0, 0, 0), v3(1, 0, 0)), RT_SHAPE_INTERSECTION);
+            auto c2 = mk_csg(std::move(c1), mk_plane(v3(0, 0, 0), v3(-angle_sin, angle_cos, 0.0f)), RT_SHAPE_INTERSECTION);
+            auto c3 = mk_csg(std::move(c2), mk_plane(v3(0, 0, half_depth), v3(0, 0, -1)), RT_SHAPE_INTERSECTION);
+            return mk_csg(std::move(c3), mk_plane(v3(0, 0, -half_depth), v3(0, 0, 1)), RT_SHAPE_INTERSECTION);
+        }
+        case RT_SHAPE_LENS: {
+            float half_thickness = sp[0] / 2.0f, r1 = sp[2], r2 = sp[3];
+            std::unique_ptr<Prim> s1, s2;
+            if (std::isfinite(r1)) {
+                auto s = std::make_unique<SpherePrim>();
+                s->center = v3(0, 0, -half_thickness + r1); s->radius = std::fabs(r1);
+                s1 = std::move(s);
+            } else {
+                s1 = mk_plane(v3(0, 0, -half_thickness), v3(0, 0, 1));
+            }
+            if (std::isfinite(r2)) {
+                auto s = std::make_unique<SpherePrim>();
+                s->center = v3(0, 0, half_thickness + r2); s->radius = std::fabs(r2);
+                s2 = std::move(s);
+            } else {
+                s2 = mk_plane(v3(0, 0, half_thickness), v3(0, 0, -1));
+            }
+            auto cyl = std::make_unique<InfCylinderPrim>();
+            cyl->axis_point = v3(0, 0, 0); cyl->axis_dir = v3(0, 0, 1); cyl->radius = sp[1] / 2.0f;
+            return mk_csg(mk_csg(std::move(s1), std::move(s2), RT_SHAPE_INTERSECTION), std::move(cyl), RT_SHAPE_INTERSECTION);
+        }
+        case RT_SHAPE_TREE: {
+            uint32_t root;
+            std::memcpy(&root, &sp[0], 4);
+            if (root >= n_nodes || depth > 32) return nullptr;
+            const RtShapeNode& n = nodes[root];
+            return build_shape(n.shape, n.shape_param, nodes, n_nodes, depth + 1);
+        }
+        case RT_SHAPE_UNION:
+        case RT_SHAPE_INTERSECTION:
+        case RT_SHAPE_DIFFERENCE: return nullptr;  // operators are reached through build_node
+    }
+    return nullptr;
+}
+std::unique_ptr<Prim> build_node(const RtShapeNode* nodes, uint64_t n_nodes, uint32_t idx, int depth)
+{
+    if (idx >= n_nodes || depth > 32) return nullptr;
+    const RtShapeNode& n = nodes[idx];
+    if (n.shape >= RT_SHAPE_UNION && n.shape <= RT_SHAPE_DIFFERENCE) {
+        auto l = build_node(nodes, n_nodes, n.a, depth + 1), r = build_node(nodes, n_nodes, n.b, depth + 1);
+        if (!l || !r) return nullptr;
+        return mk_csg(std::move(l), std::move(r), n.shape);
+    }
+    if (n.shape == RT_SHAPE_TREE) return nullptr;
+    return build_shape(n.shape, n.shape_param, nodes, n_nodes, depth + 1);
+}
+
 struct Object {  // Transform(Box<primitive>) — transform.rs:4-17, object_config.rs:16-30
     uint32_t shape;
     uint32_t mat_kind;
@@ -195,9 +481,10 @@ struct Object {  // Transform(Box<primitive>) — transform.rs:4-17, object_conf
     float radius;
     V3 normal;
     M4 transform, inverse_transform, inverse_transpose;
+    std::shared_ptr<Prim> prim;  // shapes other than Sphere / Plane
 };
 
-Object build_object(const RtObject& o)
+Object build_object(const RtObject& o, const RtShapeNode* nodes = nullptr, uint64_t n_nodes = 0)
 {
     Object r{};
     r.shape = o.shape;
@@ -206,11 +493,21 @@ Object build_object(const RtObject& o)
     r.radius = o.shape_param[0];
     r.normal = v3(o.shape_param[0], o.shape_param[1], o.shape_param[2]);
     M4 translation = from_translation(v3(o.position[0], o.position[1], o.position[2]));
-    const float rads_per_deg = 3.14159265358979323846f / 180.0f;  // f32::to_radians
-    M4 rotation = from_rotation_y(o.rotation_y_deg * rads_per_deg);
+    M4 rotation = from_rotation_y(o.rotation_y_deg * kRadsPerDeg);  // f32::to_radians
     r.transform = mul_mat4(translation, rotation);
     r.inverse_transform = inverse(r.transform);
     r.inverse_transpose = transpose(r.inverse_transform);
+    if (o.shape != RT_SHAPE_SPHERE && o.shape != RT_SHAPE_PLANE) {
+        std::unique_ptr<Prim> p;
+        if (o.shape == RT_SHAPE_TREE) {
+            uint32_t root;
+            std::memcpy(&root, &o.shape_param[0], 4);
+            p = build_node(nodes, n_nodes, root, 0);
+        } else {
+            p = build_shape(o.shape, o.shape_param, nodes, n_nodes, 0);
+        }
+        r.prim = std::move(p);
+    }
     return r;
 }
 
@@ -222,8 +519,18 @@ inline bool object_first_hit(const Object& ob, const Ray& ray, float t_min, floa
     local.origin = transform_point3(ob.inverse_transform, ray.origin);
     local.direction = transform_vector3(ob.inverse_transform, ray.direction);
     local.current_ior = ray.current_ior;
-    bool ok = (ob.shape == RT_SHAPE_SPHERE) ? sphere_first_hit(v3(0, 0, 0), ob.radius, local, t_min, t_max, out)
-                                            : plane_first_hit(v3(0, 0, 0), ob.normal, local, t_min, t_max, out);
+    bool ok;
+    if (ob.shape == RT_SHAPE_SPHERE) {
+        ok = sphere_first_hit(v3(0, 0, 0), ob.radius, local, t_min, t_max, out);
+    } else if (ob.shape == RT_SHAPE_PLANE) {
+        ok = plane_first_hit(v3(0, 0, 0), ob.normal, local, t_min, t_max, out);
+    } else {
+        if (!ob.prim) return false;
+        std::vector<Hit> hits;
+        ob.prim->intersect_all(local, t_min, t_max, hits);
+        ok = !hits.empty();
+        if (ok) out = hits.front();  // scene.rs:55 hits.first()
+    }
     if (!ok) return false;
     out.point = transform_point3(ob.transform, out.point);
     out.normal = normalize(transform_vector3(ob.inverse_transpose, out.normal));
@@ -400,13 +707,14 @@ struct orc_scene {
     Scene sc;
 };
 
-orc_scene* orc_scene_create(const RtObject* objects, uint64_t n)
+orc_scene* orc_scene_create_ex(const RtObject* objects, uint64_t n, const RtShapeNode* nodes, uint64_t n_nodes)
 {
     orc_scene* s = new orc_scene;
     s->sc.objects.reserve(n);
-    for (uint64_t k = 0; k < n; ++k) s->sc.objects.push_back(build_object(objects[k]));
+    for (uint64_t k = 0; k < n; ++k) s->sc.objects.push_back(build_object(objects[k], nodes, n_nodes));
     return s;
 }
+orc_scene* orc_scene_create(const RtObject* objects, uint64_t n) { return orc_scene_create_ex(objects, n, nullptr, 0); }
 void orc_scene_destroy(orc_scene* s) { delete s; }
 
 // Mirrors rt_hip_simulate (include/rt_hip.h).  Returns total segments.

@@ -5,6 +5,8 @@ import numpy as np
 
 RT_MAT_MIRROR, RT_MAT_GLASS, RT_MAT_HALF_MIRROR = 0, 1, 2
 RT_SHAPE_SPHERE, RT_SHAPE_PLANE = 0, 1
+RT_SHAPE_BOX, RT_SHAPE_CYLINDER, RT_SHAPE_CONE, RT_SHAPE_WEDGE, RT_SHAPE_LENS, RT_SHAPE_TREE = 2, 3, 4, 5, 6, 7
+RT_SHAPE_UNION, RT_SHAPE_INTERSECTION, RT_SHAPE_DIFFERENCE = 16, 17, 18
 RT_GEN_PARALLEL_GRID, RT_GEN_PROJECTOR = 0, 1
 
 RT_OK, RT_ERR_INVALID, RT_ERR_UNSUPPORTED, RT_ERR_HIP, RT_ERR_NOT_INIT = 0, -1, -2, -3, -4
@@ -20,6 +22,7 @@ OBJECT_DTYPE = np.dtype(
         ("shape_param", "<f4", (4,)),
     ]
 )
+NODE_DTYPE = np.dtype([("shape", "<u4"), ("a", "<u4"), ("b", "<u4"), ("shape_param", "<f4", (4,))])
 RAY_DTYPE = np.dtype([("origin", "<f4", (3,)), ("direction", "<f4", (3,)), ("current_ior", "<f4")])
 RECORD_DTYPE = np.dtype(
     [
@@ -32,6 +35,7 @@ RECORD_DTYPE = np.dtype(
         ("ior_out", "<f4"),
     ]
 )
+assert NODE_DTYPE.itemsize == 28
 assert OBJECT_DTYPE.itemsize == 44 and RAY_DTYPE.itemsize == 28 and RECORD_DTYPE.itemsize == 52
 
 

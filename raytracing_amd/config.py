@@ -48,27 +48,66 @@ def _material(t, where):
     raise ConfigError(f"{where}: unknown material type `{kind}`")
 
 
-_UNSUPPORTED_SHAPES = {"Box", "Cylinder", "Cone", "Wedge", "Lens", "Union", "Intersection", "Difference"}
+_OPS = {"Union": abi.RT_SHAPE_UNION, "Intersection": abi.RT_SHAPE_INTERSECTION, "Difference": abi.RT_SHAPE_DIFFERENCE}
 
 
-def _object(t, where, position_override=None):
-    """ObjectConfig -> one RtObject (object_config.rs:10-30, shape_config.rs:53-73)."""
+def _leaf_shape(shape, where):
+    """A non-operator ShapeConfig arm -> (RT_SHAPE_*, shape_param[4])  (shape_config.rs:11-38)."""
+    kind = _req(shape, "type", where)
+    if kind == "Sphere":
+        return abi.RT_SHAPE_SPHERE, (f32(_req(shape, "radius", where)), 0, 0, 0)
+    if kind == "Plane":
+        n = _vec3(_req(shape, "normal", where), where + ".normal")
+        return abi.RT_SHAPE_PLANE, (n[0], n[1], n[2], 0)
+    if kind == "Box":
+        sz = _vec3(_req(shape, "size", where), where + ".size")
+        return abi.RT_SHAPE_BOX, (sz[0], sz[1], sz[2], 0)
+    if kind == "Cylinder":
+        return abi.RT_SHAPE_CYLINDER, (f32(_req(shape, "height", where)), f32(_req(shape, "radius", where)), 0, 0)
+    if kind == "Cone":
+        return abi.RT_SHAPE_CONE, (f32(_req(shape, "angle_deg", where)), f32(_req(shape, "height", where)), 0, 0)
+    if kind == "Wedge":
+        sz = _vec3(_req(shape, "size", where), where + ".size")
+        return abi.RT_SHAPE_WEDGE, (sz[0], sz[1], sz[2], f32(_req(shape, "angle_deg", where)))
+    if kind == "Lens":
+        return abi.RT_SHAPE_LENS, (f32(_req(shape, "thickness", where)), f32(_req(shape, "diameter", where)),
+                                   f32(_req(shape, "r1", where)), f32(_req(shape, "r2", where)))
+    raise ConfigError(f"{where}: unknown shape type `{kind}`")
+
+
+def _shape_node(shape, where, nodes):
+    """Append the ShapeConfig subtree to `nodes` (RtShapeNode records) and return its index (shape_config.rs:39-50)."""
+    kind = _req(shape, "type", where)
+    rec = np.zeros((), abi.NODE_DTYPE)
+    if kind in _OPS:
+        a = _shape_node(_req(shape, "a", where), where + ".a", nodes)
+        b = _shape_node(_req(shape, "b", where), where + ".b", nodes)
+        rec["shape"], rec["a"], rec["b"] = _OPS[kind], a, b
+    else:
+        rec["shape"], sp = _leaf_shape(shape, where)
+        rec["shape_param"] = sp
+    nodes.append(rec)
+    return len(nodes) - 1
+
+
+def _object(t, where, position_override=None, nodes=None):
+    """ObjectConfig -> one RtObject (object_config.rs:10-30, shape_config.rs:53-149)."""
     shape = _req(t, "shape", where)
     mat = _req(t, "material", where)
     tr = _req(t, "transform", where)
     o = np.zeros((), abi.OBJECT_DTYPE)
     kind = _req(shape, "type", where + ".shape")
-    if kind == "Sphere":
-        o["shape"] = abi.RT_SHAPE_SPHERE
-        o["shape_param"] = (f32(_req(shape, "radius", where + ".shape")), 0, 0, 0)
-    elif kind == "Plane":
-        n = _vec3(_req(shape, "normal", where + ".shape"), where + ".shape.normal")
-        o["shape"] = abi.RT_SHAPE_PLANE
-        o["shape_param"] = (n[0], n[1], n[2], 0)
-    elif kind in _UNSUPPORTED_SHAPES:
-        raise NotImplementedError(f"{where}: shape `{kind}` exists in the reference (shape_config.rs) but is not on the GPU path yet")
+    if kind in _OPS:
+        if nodes is None:
+            raise ConfigError(f"{where}: CSG tree needs a node list")
+        root = _shape_node(shape, where + ".shape", nodes)
+        o["shape"] = abi.RT_SHAPE_TREE
+        sp = np.zeros(4, f32)
+        sp.view(np.uint32)[0] = root
+        o["shape_param"] = sp
     else:
-        raise ConfigError(f"{where}: unknown shape type `{kind}`")
+        o["shape"], sp = _leaf_shape(shape, where + ".shape")
+        o["shape_param"] = sp
     o["material_kind"], o["material_param"] = _material(mat, where + ".material")
     pos = _vec3(_req(tr, "position", where + ".transform"), where + ".transform.position")
     o["position"] = pos if position_override is None else position_override
@@ -93,7 +132,12 @@ class SceneConfig:
 
     def object_list(self):
         """scene_config.rs:25-52 -> numpy array of RtObject in `Scene.objects` order."""
-        out = [_object(t, f"scene.objects[{k}]") for k, t in enumerate(self.objects)]
+        return self.object_and_node_lists()[0]
+
+    def object_and_node_lists(self):
+        """(objects, nodes): nodes hold the Union/Intersection/Difference trees that RT_SHAPE_TREE objects point into."""
+        nodes = []
+        out = [_object(t, f"scene.objects[{k}]", nodes=nodes) for k, t in enumerate(self.objects)]
         for g, gen in enumerate(self.object_generators):
             where = f"scene.object_generators[{g}]"
             kind = _req(gen, "type", where)
@@ -106,10 +150,10 @@ class SceneConfig:
             for i in range(int(_req(gen, "count_x", where))):
                 for j in range(int(_req(gen, "count_z", where))):
                     pos = ((start + f32(i) * sx).astype(f32) + f32(j) * sz).astype(f32)  # scene_config.rs:44
-                    out.append(_object(template, where + ".template", position_override=pos))
-        if not out:
-            return np.zeros(0, abi.OBJECT_DTYPE)
-        return np.array(out, dtype=abi.OBJECT_DTYPE)
+                    out.append(_object(template, where + ".template", position_override=pos, nodes=nodes))
+        objs = np.array(out, dtype=abi.OBJECT_DTYPE) if out else np.zeros(0, abi.OBJECT_DTYPE)
+        nds = np.array(nodes, dtype=abi.NODE_DTYPE) if nodes else np.zeros(0, abi.NODE_DTYPE)
+        return objs, nds
 
     def generators(self):
         """RayGeneratorConfig list as C-ABI RtRayGenerator structs (object_generator_config.rs:13-33)."""
@@ -164,7 +208,8 @@ class SceneConfig:
         """`let scene: Scene = scene.into();` (cli.rs:13) — uploads the object list to the GPU."""
         from .engine import Scene
 
-        return Scene(self.object_list(), self.ray_list())
+        objs, nodes = self.object_and_node_lists()
+        return Scene(objs, self.ray_list(), nodes=nodes)
 
 
 @dataclass

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "rt_host_shapes.h"
 #include "rt_internal.h"
 
 namespace {
@@ -225,9 +226,15 @@ int rt_hip_set_scan_mode(int mode)
 
 int rt_hip_scene_create(const RtObject* objects, uint64_t n_objects, rt_scene** out_scene)
 {
+    return rt_hip_scene_create_ex(objects, n_objects, nullptr, 0, out_scene);
+}
+
+int rt_hip_scene_create_ex(const RtObject* objects, uint64_t n_objects, const RtShapeNode* shape_nodes, uint64_t n_shape_nodes,
+                           rt_scene** out_scene)
+{
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_ctx.ready) return fail(RT_ERR_NOT_INIT, "rt_hip_init() has not been called");
-    if (!out_scene || (!objects && n_objects)) return fail(RT_ERR_INVALID, "null argument");
+    if (!out_scene || (!objects && n_objects) || (!shape_nodes && n_shape_nodes)) return fail(RT_ERR_INVALID, "null argument");
     if (n_objects >= (1ull << 23)) return fail(RT_ERR_INVALID, "too many objects (limit 2^23)");
     *out_scene = nullptr;
 
@@ -235,18 +242,42 @@ int rt_hip_scene_create(const RtObject* objects, uint64_t n_objects, rt_scene** 
     std::vector<int32_t> sph_obj, pl_obj;
     std::vector<uint2> obj_mat(n_objects);
     std::vector<uint32_t> obj_shape(n_objects);
+    std::vector<rt::CxNode> cx_nodes;
+    std::vector<rt::CxObject> cx_objs;
     double c2max = 0.0;
     for (uint64_t k = 0; k < n_objects; ++k) {
         const RtObject& o = objects[k];
         if (o.material_kind > RT_MAT_HALF_MIRROR) return fail(RT_ERR_INVALID, "object " + std::to_string(k) + ": unknown material kind");
-        if (o.rotation_y_deg != 0.0f)
-            return fail(RT_ERR_UNSUPPORTED, "object " + std::to_string(k) + ": rotation_y_deg != 0 is not on the GPU path yet");
         uint32_t pbits;
         std::memcpy(&pbits, &o.material_param, 4);
         obj_mat[k] = make_uint2(o.material_kind, pbits);
         obj_shape[k] = o.shape;
         const float px = o.position[0], py = o.position[1], pz = o.position[2];
-        if (o.shape == RT_SHAPE_SPHERE) {
+        // Spheres and planes with rotation 0 fold their Transform exactly and ride the scan path;
+        // every other object is evaluated per lane with the reference's intersect_all (rt_complex.h).
+        const bool fast = (o.shape == RT_SHAPE_SPHERE || o.shape == RT_SHAPE_PLANE) && o.rotation_y_deg == 0.0f;
+        if (!fast) {
+            rt::host::Program pr;
+            std::string err;
+            if (rt::host::emit_shape(o.shape, o.shape_param, shape_nodes, n_shape_nodes, pr, 0, 0, err) < 0)
+                return fail(RT_ERR_INVALID, "object " + std::to_string(k) + ": " + err);
+            if (pr.max_hits > rt::kCxMaxHits || pr.max_stack > rt::kCxStack)
+                return fail(RT_ERR_UNSUPPORTED, "object " + std::to_string(k) + ": shape tree needs " + std::to_string(pr.max_hits) +
+                                                    " hits / stack " + std::to_string(pr.max_stack) + " (limits " +
+                                                    std::to_string(rt::kCxMaxHits) + " / " + std::to_string(rt::kCxStack) + ")");
+            rt::CxObject co{};
+            co.first_node = (uint32_t)cx_nodes.size();
+            co.n_nodes = (uint32_t)pr.nodes.size();
+            co.obj_id = (int32_t)k;
+            rt::host::Mat4 m, mi;
+            rt::host::object_matrices(o, m, mi);
+            std::memcpy(co.m, m.c, sizeof co.m);
+            std::memcpy(co.minv, mi.c, sizeof co.minv);
+            cx_nodes.insert(cx_nodes.end(), pr.nodes.begin(), pr.nodes.end());
+            cx_objs.push_back(co);
+            obj_geom[k] = make_float4(px, py, pz, 0);
+            obj_aux[k] = make_float4(0, 0, 0, 0);
+        } else if (o.shape == RT_SHAPE_SPHERE) {
             const float r = o.shape_param[0];
             const double pp = (double)px * px + (double)py * py + (double)pz * pz;
             const double rr = (double)r * r;
@@ -262,8 +293,6 @@ int rt_hip_scene_create(const RtObject* objects, uint64_t n_objects, rt_scene** 
             pl_obj.push_back((int32_t)k);
             obj_geom[k] = make_float4(px, py, pz, 0);
             obj_aux[k] = make_float4(o.shape_param[0], o.shape_param[1], o.shape_param[2], 0);
-        } else {
-            return fail(RT_ERR_UNSUPPORTED, "object " + std::to_string(k) + ": shape is not on the GPU path yet (Sphere and Plane are)");
         }
     }
     const uint32_t n_sph = (uint32_t)sph_cull.size();
@@ -297,6 +326,8 @@ int rt_hip_scene_create(const RtObject* objects, uint64_t n_objects, rt_scene** 
     up(obj_aux, &d.obj_aux);
     up(obj_mat, &d.obj_mat);
     up(obj_shape, &d.obj_shape);
+    up(cx_nodes, &d.cx_nodes);
+    up(cx_objs, &d.cx_objs);
     if (e != hipSuccess) {
         free_scene(s);
         return fail_hip(e, "scene upload");
@@ -305,6 +336,7 @@ int rt_hip_scene_create(const RtObject* objects, uint64_t n_objects, rt_scene** 
     d.n_sph_pad = n_pad;
     d.n_pl = (uint32_t)pl_pos.size();
     d.n_obj = (uint32_t)n_objects;
+    d.n_cx = (uint32_t)cx_objs.size();
     d.c2max = c2max_f;
     s->host_spheres.assign(sph_exact.begin(), sph_exact.begin() + n_sph);
     *out_scene = s;

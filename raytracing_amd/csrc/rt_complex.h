@@ -1,0 +1,268 @@
+// rt_complex.h — per-lane evaluation of the objects that are not on the sphere / plane scan path:
+// AxisAlignedBox (axis_aligned_box.rs:12-95), InfiniteCylinder (infinite_cylinder.rs:13-84), InfiniteCone
+// (infinite_cone.rs:26-86), CSGObject (csg.rs:9-75) and the shapes assembled from them (shape_config.rs:74-149,
+// wedge.rs:10-78, lens.rs:11-76), each inside a general Transform (transform.rs:20-51; T(position) * R_y(deg)).
+// Rotated spheres and planes take this path too.
+//
+// Such objects are few, so every lane walks them one after the other after the sphere scan, with the reference's
+// own intersect_all: leaf hit lists, stable sort by t, the in/out state machine, hits.first().  Children are
+// evaluated with t_max = +inf and the object then competes through the same (t, obj_id) key as everything else;
+// compared with the reference's shrinking t_max this can only differ when two child surfaces coincide within
+// the 1e-6 window of csg.rs:33 exactly at the current closest t.
+#pragma once
+#include "rt_device.h"
+
+namespace rt {
+namespace {
+
+struct CxHit {
+    float t;
+    F3 p, n;
+    uint32_t ff;
+};
+
+// glam Mat4 (column-major) products in the reference's association order.
+__device__ __forceinline__ F3 xf_point(const float* m, F3 v)
+{
+    return f3(((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[12], ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[13],
+              ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[14]);
+}
+__device__ __forceinline__ F3 xf_vector(const float* m, F3 v)
+{
+    return f3((m[0] * v.x + m[4] * v.y) + m[8] * v.z, (m[1] * v.x + m[5] * v.y) + m[9] * v.z, (m[2] * v.x + m[6] * v.y) + m[10] * v.z);
+}
+// transform_vector3 of the transposed inverse (transform.rs:39-43)
+__device__ __forceinline__ F3 xf_normal(const float* minv, F3 n)
+{
+    return f3((minv[0] * n.x + minv[1] * n.y) + minv[2] * n.z, (minv[4] * n.x + minv[5] * n.y) + minv[6] * n.z,
+              (minv[8] * n.x + minv[9] * n.y) + minv[10] * n.z);
+}
+
+__device__ __forceinline__ float comp(F3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+
+__device__ __forceinline__ void cx_push_quadric(CxHit* out, int& n, float t, F3 o, F3 d, F3 outward)
+{
+    bool front = dot(d, outward) < 0.0f;
+    out[n].t = t;
+    out[n].p = o + t * d;
+    out[n].n = front ? outward : -outward;
+    out[n].ff = front ? 1u : 0u;
+    ++n;
+}
+
+// One leaf's intersect_all(ray, 0.001, +inf): hits in the order the reference pushes them.
+__device__ __noinline__ int cx_leaf(const CxNode nd, F3 o, F3 d, CxHit* out)
+{
+    int n = 0;
+    const float inf = __builtin_inff();
+    const F3 A = f3(nd.a.x, nd.a.y, nd.a.z), B = f3(nd.b.x, nd.b.y, nd.b.z);
+    if (nd.kind == CX_SPHERE) {  // sphere.rs:12-74
+        const float radius = nd.a.w;
+        F3 oc = o - A;
+        float a = dot(d, d);
+        float half_b = dot(oc, d);
+        float c = dot(oc, oc) - radius * radius;
+        float disc = half_b * half_b - a * c;
+        if (disc < 0.0f) return 0;
+        float sqrtd = __builtin_sqrtf(disc);
+        float t1 = (-half_b - sqrtd) / a;
+        if (t1 > kTMin && t1 < inf) cx_push_quadric(out, n, t1, o, d, ((o + t1 * d) - A) / radius);
+        if (disc > 1e-6f) {
+            float t2 = (-half_b + sqrtd) / a;
+            if (t2 > kTMin && t2 < inf) cx_push_quadric(out, n, t2, o, d, ((o + t2 * d) - A) / radius);
+        }
+    } else if (nd.kind == CX_PLANE) {  // plane.rs:12-54
+        float denom = dot(B, d);
+        if (__builtin_fabsf(denom) < 1e-6f) return 0;
+        float t = dot(A - o, B) / denom;
+        if (t < kTMin || inf < t) return 0;  // NaN passes, exactly like the reference's test
+        bool front = dot(d, B) < 0.0f;
+        out[0].t = t;
+        out[0].p = o + t * d;
+        out[0].n = front ? B : -B;
+        out[0].ff = front ? 1u : 0u;
+        n = 1;
+    } else if (nd.kind == CX_BOX) {  // axis_aligned_box.rs:12-95
+        float tmin = kTMin, tmax = inf;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float inv_d = 1.0f / comp(d, i);
+            float t0 = (comp(A, i) - comp(o, i)) * inv_d;
+            float t1 = (comp(B, i) - comp(o, i)) * inv_d;
+            if (inv_d < 0.0f) {
+                float s = t0;
+                t0 = t1;
+                t1 = s;
+            }
+            tmin = __builtin_fmaxf(tmin, t0);
+            tmax = __builtin_fminf(tmax, t1);
+            if (tmax <= tmin) return 0;
+        }
+        const float ts[2] = {tmin, tmax};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            F3 p = o + ts[k] * d;
+            F3 pa = p - A, pb = p - B;
+            const float eps = 1e-4f;
+            F3 nn = f3(0.f, 0.f, 0.f);
+            if (__builtin_fabsf(pa.x) < eps) nn = f3(-1.f, 0.f, 0.f);
+            else if (__builtin_fabsf(pb.x) < eps) nn = f3(1.f, 0.f, 0.f);
+            else if (__builtin_fabsf(pa.y) < eps) nn = f3(0.f, -1.f, 0.f);
+            else if (__builtin_fabsf(pb.y) < eps) nn = f3(0.f, 1.f, 0.f);
+            else if (__builtin_fabsf(pa.z) < eps) nn = f3(0.f, 0.f, -1.f);
+            else if (__builtin_fabsf(pb.z) < eps) nn = f3(0.f, 0.f, 1.f);
+            if (k == 1) nn = -nn;  // exit normal points inward (axis_aligned_box.rs:56)
+            out[k].t = ts[k];
+            out[k].p = p;
+            out[k].n = nn;
+            out[k].ff = dot(d, nn) < 0.0f ? 1u : 0u;
+        }
+        n = 2;
+    } else if (nd.kind == CX_INFCYL) {  // infinite_cylinder.rs:13-84 (A = axis_point, B = axis_dir, a.w = radius)
+        const float radius = nd.a.w;
+        F3 oc = o - A;
+        float d_dot_v = dot(d, B);
+        F3 d_perp = d - d_dot_v * B;
+        float oc_dot_v = dot(oc, B);
+        F3 oc_perp = oc - oc_dot_v * B;
+        float a = dot(d_perp, d_perp);
+        float b = 2.0f * dot(oc_perp, d_perp);
+        float c = dot(oc_perp, oc_perp) - radius * radius;
+        if (__builtin_fabsf(a) < 1e-6f) return 0;
+        float disc = b * b - 4.0f * a * c;
+        if (disc < 0.0f) return 0;
+        float sqrtd = __builtin_sqrtf(disc);
+        const float ts[2] = {(-b - sqrtd) / (2.0f * a), (-b + sqrtd) / (2.0f * a)};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float t = ts[k];
+            if (t > kTMin && t < inf) {
+                F3 p = o + t * d;
+                F3 pma = p - A;
+                float proj = dot(pma, B);
+                F3 on_axis = A + proj * B;
+                cx_push_quadric(out, n, t, o, d, normalize(p - on_axis));
+            }
+        }
+    } else if (nd.kind == CX_INFCONE) {  // infinite_cone.rs:26-86 (A = vertex, B = axis_dir, a.w = cos^2)
+        const float cs = nd.a.w;
+        F3 co = o - A;
+        float d_dot_v = dot(d, B);
+        float co_dot_v = dot(co, B);
+        float a = d_dot_v * d_dot_v - cs;
+        float b = 2.0f * (d_dot_v * co_dot_v - dot(d, co) * cs);
+        float c = co_dot_v * co_dot_v - dot(co, co) * cs;
+        float disc = b * b - 4.0f * a * c;
+        if (disc < 0.0f) return 0;
+        float sqrtd = __builtin_sqrtf(disc);
+        const float ts[2] = {(-b - sqrtd) / (2.0f * a), (-b + sqrtd) / (2.0f * a)};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float t = ts[k];
+            if (t > kTMin && t < inf) {
+                F3 p = o + t * d;
+                F3 pv = p - A;
+                float m = dot(pv, B);
+                cx_push_quadric(out, n, t, o, d, normalize(m * B - pv * cs));
+            }
+        }
+    }
+    return n;
+}
+
+__device__ __forceinline__ bool cx_inside(uint32_t op, bool l, bool r)
+{
+    return op == CX_UNION ? (l || r) : (op == CX_INTERSECTION ? (l && r) : (l && !r));
+}
+
+// csg.rs:9-75 on two child lists; result in `out` (capacity checked on the host: nl + nr <= kCxMaxHits).
+__device__ __noinline__ int cx_combine(uint32_t op, const CxHit* L, int nl, const CxHit* Rr, int nr, CxHit* out)
+{
+    CxHit all[kCxMaxHits];
+    int na = 0;
+    for (int i = 0; i < nl; ++i) all[na++] = L[i];
+    for (int i = 0; i < nr; ++i) all[na++] = Rr[i];
+    // stable insertion sort by t (sort_by(partial_cmp), csg.rs:23)
+    for (int i = 1; i < na; ++i) {
+        CxHit x = all[i];
+        int j = i;
+        while (j > 0 && all[j - 1].t > x.t) {
+            all[j] = all[j - 1];
+            --j;
+        }
+        all[j] = x;
+    }
+    bool in_left = false, in_right = false;
+    int no = 0;
+    for (int i = 0; i < na; ++i) {
+        bool on_left = false;
+        for (int k = 0; k < nl; ++k) on_left = on_left || (__builtin_fabsf(L[k].t - all[i].t) < 1e-6f);
+        bool was = cx_inside(op, in_left, in_right);
+        if (on_left) in_left = !in_left;
+        else in_right = !in_right;
+        bool is = cx_inside(op, in_left, in_right);
+        if (was != is) {
+            CxHit h = all[i];
+            if (op == CX_DIFFERENCE && !on_left) {
+                h.n = -h.n;
+                h.ff = h.ff ? 0u : 1u;
+            }
+            out[no++] = h;
+        }
+    }
+    return no;
+}
+
+// hits.first() of Transform(object).intersect_all(ray, 0.001, +inf), still in the object's local space.
+__device__ __noinline__ bool cx_first_hit(const DevScene& sc, const CxObject& ob, F3 o, F3 d, CxHit& first)
+{
+    const F3 lo = xf_point(ob.minv, o);
+    const F3 ld = xf_vector(ob.minv, d);
+    CxHit st[kCxStack][kCxMaxHits];
+    int cnt[kCxStack];
+    int sp = 0;
+    for (uint32_t k = 0; k < ob.n_nodes; ++k) {
+        const CxNode nd = sc.cx_nodes[ob.first_node + k];
+        if (nd.kind < CX_UNION) {
+            cnt[sp] = cx_leaf(nd, lo, ld, st[sp]);
+            ++sp;
+        } else {
+            CxHit tmp[kCxMaxHits];
+            int n = cx_combine(nd.kind, st[sp - 2], cnt[sp - 2], st[sp - 1], cnt[sp - 1], tmp);
+            sp -= 2;
+            for (int i = 0; i < n; ++i) st[sp][i] = tmp[i];
+            cnt[sp] = n;
+            ++sp;
+        }
+    }
+    if (cnt[0] == 0) return false;
+    first = st[0][0];
+    return true;
+}
+
+// Merge every complex object into the running closest-hit key; remember the winner's local hit record.
+__device__ __forceinline__ unsigned long long cx_min_key(const DevScene& sc, F3 o, F3 d, unsigned long long key, CxHit& best, int& best_cx)
+{
+    for (uint32_t k = 0; k < sc.n_cx; ++k) {
+        CxHit h;
+        if (cx_first_hit(sc, sc.cx_objs[k], o, d, h) && h.t < __builtin_inff()) {  // scene.rs:56; NaN / inf never win
+            unsigned long long kk = pack_key(h.t, sc.cx_objs[k].obj_id);
+            if (kk < key) {
+                key = kk;
+                best = h;
+                best_cx = (int)k;
+            }
+        }
+    }
+    return key;
+}
+
+// World-space record of a complex winner (transform.rs:33-46).
+__device__ __forceinline__ void cx_to_world(const CxObject& ob, const CxHit& h, F3& point, F3& normal)
+{
+    point = xf_point(ob.m, h.p);
+    normal = normalize(xf_normal(ob.minv, h.n));
+}
+
+}  // namespace
+}  // namespace rt

@@ -336,30 +336,42 @@ struct Shade {
     float ior;  // new current_ior
     F3 o_next;  // scene.rs:97
 };
+// `pre` (optional): the winner came from the complex-object path, its world point / normal / front_face are given.
+struct PreHit {
+    bool valid;
+    F3 point, normal;
+    bool front;
+};
 __device__ __forceinline__ Shade shade_hit(const DevScene& sc, F3 o, F3 d, float ior, unsigned long long key, uint64_t seed,
-                                           uint64_t path_id, uint32_t bounce)
+                                           uint64_t path_id, uint32_t bounce, const PreHit& pre)
 {
     Shade h;
     h.obj = (int32_t)(uint32_t)(key & 0xffffffffull);
     h.t = __uint_as_float((uint32_t)(key >> 32));
-    const float4 g = sc.obj_geom[h.obj];
     const uint2 mat = sc.obj_mat[h.obj];
-    const F3 pos = f3(g.x, g.y, g.z);
-    const F3 lo = o - pos;
-    const F3 pl = lo + h.t * d;  // local hit point (sphere.rs:28 / plane.rs:32)
-    F3 nl;
-    if (sc.obj_shape[h.obj] == RT_SHAPE_SPHERE) {
-        F3 outward = pl / g.w;  // (point - 0) / radius, sphere.rs:29
-        h.front = dot(d, outward) < 0.0f;
-        nl = h.front ? outward : -outward;
+    if (pre.valid) {
+        h.point = pre.point;
+        h.normal = pre.normal;
+        h.front = pre.front;
     } else {
-        float4 n4 = sc.obj_aux[h.obj];
-        F3 n = f3(n4.x, n4.y, n4.z);
-        h.front = dot(d, n) < 0.0f;
-        nl = h.front ? n : -n;
+        const float4 g = sc.obj_geom[h.obj];
+        const F3 pos = f3(g.x, g.y, g.z);
+        const F3 lo = o - pos;
+        const F3 pl = lo + h.t * d;  // local hit point (sphere.rs:28 / plane.rs:32)
+        F3 nl;
+        if (sc.obj_shape[h.obj] == RT_SHAPE_SPHERE) {
+            F3 outward = pl / g.w;  // (point - 0) / radius, sphere.rs:29
+            h.front = dot(d, outward) < 0.0f;
+            nl = h.front ? outward : -outward;
+        } else {
+            float4 n4 = sc.obj_aux[h.obj];
+            F3 n = f3(n4.x, n4.y, n4.z);
+            h.front = dot(d, n) < 0.0f;
+            nl = h.front ? n : -n;
+        }
+        h.point = pl + pos;        // transform.rs:37 (M = T(position))
+        h.normal = normalize(nl);  // transform.rs:39-43
     }
-    h.point = pl + pos;        // transform.rs:37 (M = T(position))
-    h.normal = normalize(nl);  // transform.rs:39-43
     h.dn = d;
     h.ior = ior;
     if (mat.x == RT_MAT_MIRROR) {

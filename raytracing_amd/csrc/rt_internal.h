@@ -12,6 +12,23 @@ constexpr int kBlockThreads = 256;  // 4 waves
 constexpr uint32_t kUnitSamples = 8;  // samples of one cell traced back to back by one lane (render work unit)
 constexpr int kUnroll = 4;          // spheres per scan step; sphere arrays are padded to a multiple
 
+// ---- objects off the scan path (rt_complex.h): post-order node programs evaluated per lane ----
+enum : uint32_t { CX_SPHERE = 0, CX_PLANE = 1, CX_BOX = 2, CX_INFCYL = 3, CX_INFCONE = 4, CX_UNION = 16, CX_INTERSECTION = 17, CX_DIFFERENCE = 18 };
+constexpr int kCxMaxHits = 8;  // hits a node's list may hold (checked when the scene is built)
+constexpr int kCxStack = 4;    // list stack depth of the post-order evaluation (checked likewise)
+struct CxNode {
+    uint32_t kind, pad0, pad1, pad2;
+    float4 a;  // sphere: centre, radius | plane: point | box: min | cylinder: axis point, radius | cone: vertex, cos^2
+    float4 b;  // plane: normal | box: max | cylinder / cone: axis direction
+};
+struct CxObject {
+    uint32_t first_node, n_nodes;
+    int32_t obj_id;
+    uint32_t pad;
+    float m[16];     // Transform.transform          (column-major, glam Mat4)
+    float minv[16];  // Transform.inverse_transform
+};
+
 // Flattened scene as the kernels see it (all pointers are device memory).
 struct DevScene {
     const float4* sph_cull;   // [n_sph_pad] {px, py, pz, K = |p|^2 - r^2}; padding has K = +inf
@@ -24,6 +41,9 @@ struct DevScene {
     const float4* obj_aux;    // [n_obj] plane: {nx,ny,nz,0}
     const uint2* obj_mat;     // [n_obj] {material kind, bits of material param}
     const uint32_t* obj_shape;  // [n_obj]
+    const CxNode* cx_nodes;     // node programs of the complex objects
+    const CxObject* cx_objs;    // [n_cx]
+    uint32_t n_cx;
     uint32_t n_sph, n_sph_pad, n_pl, n_obj;
     float c2max;  // >= max_j (|p_j|^2 + r_j^2), rounded up: magnitude bound used by the cull margin
 };

@@ -21,7 +21,7 @@
 // Everything outside the filter is compiled without FP contraction (-ffp-contract=off) so that it rounds
 // exactly like the reference's scalar f32 code; the filter uses explicit fmaf and is protected by the
 // error bound derived in DESIGN.md ("Conservative filter").
-#include "rt_device.h"
+#include "rt_complex.h"
 
 #include <cstdlib>
 
@@ -32,7 +32,9 @@ namespace {
 // STREAM = false: the sphere table (<= kTileSpheres) is staged in LDS once per block.
 // STREAM = true : larger scenes; every wave streams the table from global memory / L2 (scan_tile<.., PF = true>).
 // Waves never synchronise with each other after the table is staged.
-template <int R, int MODE, bool STREAM>
+// CX = the scene holds objects of the per-lane complex path (rt_complex.h); kept out of the other instantiations
+// so they carry no private-memory frame.
+template <int R, int MODE, bool STREAM, bool CX>
 __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams p)
 {
     __shared__ float4 tile[STREAM ? 1 : kTileSpheres];
@@ -166,6 +168,18 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             unsigned long long key = w.best[slot];
             const F3 o = s[r].o, d = s[r].d;
             key = planes_min_key(sc, o, d, key);
+            PreHit pre;
+            pre.valid = false;
+            if (CX) {
+                CxHit ch;
+                int ci = -1;
+                key = cx_min_key(sc, o, d, key, ch, ci);
+                if (ci >= 0) {
+                    pre.valid = true;
+                    pre.front = ch.ff != 0;
+                    cx_to_world(sc.cx_objs[ci], ch, pre.point, pre.normal);
+                }
+            }
             ++s[r].segs;
             ++my_segments;
             const uint32_t b = s[r].bounce;
@@ -175,48 +189,15 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             F3 value = f3(0, 0, 0);
             RtBounceRecord rec;
             if (key != kNoHit) {
-                const int32_t obj = (int32_t)(uint32_t)(key & 0xffffffffull);
-                const float t = __uint_as_float((uint32_t)(key >> 32));
-                const float4 g = sc.obj_geom[obj];
-                const uint2 mat = sc.obj_mat[obj];
-                const F3 pos = f3(g.x, g.y, g.z);
-                const F3 lo = o - pos;
-                const F3 pl = lo + t * d;  // local hit point (sphere.rs:28 / plane.rs:32)
-                F3 nl;
-                bool front;
-                if (sc.obj_shape[obj] == RT_SHAPE_SPHERE) {
-                    F3 outward = pl / g.w;  // (point - 0) / radius, sphere.rs:29
-                    front = dot(d, outward) < 0.0f;
-                    nl = front ? outward : -outward;
-                } else {
-                    float4 n4 = sc.obj_aux[obj];
-                    F3 n = f3(n4.x, n4.y, n4.z);
-                    front = dot(d, n) < 0.0f;
-                    nl = front ? n : -n;
-                }
-                const F3 point = pl + pos;        // transform.rs:37 (M = T(position))
-                const F3 normal = normalize(nl);  // transform.rs:39-43
-                F3 dn = d;
-                float ior = s[r].ior;
-                if (mat.x == RT_MAT_MIRROR) {
-                    dn = reflect(d, normal);
-                } else if (mat.x == RT_MAT_GLASS) {
-                    float n1 = ior;
-                    float n2 = front ? __uint_as_float(mat.y) : 1.0f;
-                    float ratio = n1 / n2;
-                    F3 refr;
-                    if (refract(d, normal, ratio, refr)) {
-                        dn = refr;
-                        ior = n2;
-                    } else {
-                        dn = reflect(d, normal);
-                    }
-                } else {
-                    if (uniform01(p.seed, path_id, b) < __uint_as_float(mat.y)) dn = reflect(d, normal);
-                }
+                const Shade sh = shade_hit(sc, o, d, s[r].ior, key, p.seed, path_id, b, pre);
+                const int32_t obj = sh.obj;
+                const float t = sh.t;
+                const F3 point = sh.point, normal = sh.normal, dn = sh.dn;
+                const bool front = sh.front;
+                const float ior = sh.ior;
                 s[r].d = dn;
                 s[r].ior = ior;
-                s[r].o = point + dn * kReorigin;
+                s[r].o = sh.o_next;
                 if (p.points) {
                     float* pt = p.points + ((uint64_t)s[r].m * stride_pts + s[r].np) * 3;
                     pt[0] = point.x; pt[1] = point.y; pt[2] = point.z;
@@ -313,11 +294,11 @@ static int blocks_per_cu(K kernel)
     return n;
 }
 
-template <int MODE, bool STREAM>
+template <int MODE, bool STREAM, bool CX>
 static hipError_t launch_trace_t(const TraceParams& p, int n_cu, hipStream_t stream)
 {
     constexpr int R = 2;
-    static const int occ = blocks_per_cu(trace_kernel<R, MODE, STREAM>);
+    static const int occ = blocks_per_cu(trace_kernel<R, MODE, STREAM, CX>);
     // persistent grid: exactly the resident capacity (every block pulls units until the counter runs out),
     // never more blocks than the work can feed
     const uint64_t slots_per_block = (uint64_t)kBlockThreads * R;
@@ -325,15 +306,20 @@ static hipError_t launch_trace_t(const TraceParams& p, int n_cu, hipStream_t str
     const uint64_t cap = (uint64_t)n_cu * occ;
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL((trace_kernel<R, MODE, STREAM>), dim3(blocks), dim3(kBlockThreads), 0, stream, p);
+    hipLaunchKernelGGL((trace_kernel<R, MODE, STREAM, CX>), dim3(blocks), dim3(kBlockThreads), 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_trace(const TraceParams& p, int n_cu, hipStream_t stream)
 {
     const bool stream_table = p.sc.n_sph_pad > (uint32_t)kTileSpheres;
-    if (p.scan_mode == 0) return stream_table ? launch_trace_t<0, true>(p, n_cu, stream) : launch_trace_t<0, false>(p, n_cu, stream);
-    return stream_table ? launch_trace_t<1, true>(p, n_cu, stream) : launch_trace_t<1, false>(p, n_cu, stream);
+    const bool cx = p.sc.n_cx > 0;
+    if (p.scan_mode == 0) {
+        if (cx) return stream_table ? launch_trace_t<0, true, true>(p, n_cu, stream) : launch_trace_t<0, false, true>(p, n_cu, stream);
+        return stream_table ? launch_trace_t<0, true, false>(p, n_cu, stream) : launch_trace_t<0, false, false>(p, n_cu, stream);
+    }
+    if (cx) return stream_table ? launch_trace_t<1, true, true>(p, n_cu, stream) : launch_trace_t<1, false, true>(p, n_cu, stream);
+    return stream_table ? launch_trace_t<1, true, false>(p, n_cu, stream) : launch_trace_t<1, false, false>(p, n_cu, stream);
 }
 
 hipError_t launch_finalize(const unsigned long long* fb_q, float* fb, uint64_t n_values, uint32_t spp, hipStream_t stream)

@@ -8,7 +8,7 @@
 // one general scan step for them (same code as trace_kernel).  Both step kinds therefore run with every lane
 // busy.  Path values of primary misses are summed per work unit in registers; continuing paths add their
 // value and segment count with global atomics when they end (fixed-point sums: order-independent).
-#include "rt_device.h"
+#include "rt_complex.h"
 
 #include <cstdlib>
 
@@ -40,7 +40,7 @@ __global__ void pinhole_table_kernel(const TraceParams p, float4* table)
 }
 
 // STREAM = false: both tables (<= kTileSpheres spheres) live in LDS.  STREAM = true: both are streamed from global / L2.
-template <int R, bool STREAM>
+template <int R, bool STREAM, bool CX>
 __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TraceParams p)
 {
     extern __shared__ float4 tiles[];  // [n_sph_pad] general {p, K}  then  [n_sph_pad] pinhole {p - O, sK}  (LDS mode)
@@ -203,13 +203,25 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
             if (live[r]) {
                 const unsigned slot = r * 64 + lane;
                 unsigned long long key = planes_min_key(sc, ro[r], rd[r], w.best[slot]);
+                PreHit pre;
+                pre.valid = false;
+                if (CX) {
+                    CxHit ch;
+                    int ci = -1;
+                    key = cx_min_key(sc, ro[r], rd[r], key, ch, ci);
+                    if (ci >= 0) {
+                        pre.valid = true;
+                        pre.front = ch.ff != 0;
+                        cx_to_world(sc.cx_objs[ci], ch, pre.point, pre.normal);
+                    }
+                }
                 ++my_segments;
                 const uint32_t b = rb[r];
                 const uint64_t path_id = (p.cell_begin + (uint64_t)rm[r] * p.cell_step) * (uint64_t)p.spp + rsample[r];
                 bool ended = false;
                 F3 value = f3(0.f, 0.f, 0.f);
                 if (key != kNoHit) {
-                    h = shade_hit(sc, ro[r], rd[r], rior[r], key, p.seed, path_id, b);
+                    h = shade_hit(sc, ro[r], rd[r], rior[r], key, p.seed, path_id, b, pre);
                     if (b == 0 && rsample[r] == 0) {
                         if (p.first_id) p.first_id[rm[r]] = h.obj;
                         if (p.first_t) p.first_t[rm[r]] = h.t;
@@ -286,11 +298,11 @@ constexpr int kR = 2;
 inline bool stream_mode(const TraceParams& p) { return p.sc.n_sph_pad > (uint32_t)kTileSpheres; }
 inline size_t dyn_lds(const TraceParams& p) { return stream_mode(p) ? 0 : (size_t)p.sc.n_sph_pad * sizeof(float4) * 2; }
 
-template <bool STREAM>
+template <bool STREAM, bool CX>
 int pinhole_blocks_per_cu(size_t dyn_bytes)
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pinhole_kernel<kR, STREAM>, kPinThreads, dyn_bytes) != hipSuccess || n < 1) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pinhole_kernel<kR, STREAM, CX>, kPinThreads, dyn_bytes) != hipSuccess || n < 1) n = 1;
     if (const char* e = getenv("RT_HIP_BLOCKS_PER_CU")) {  // tuning knob
         int v = atoi(e);
         if (v >= 1 && v <= 8) n = v;
@@ -303,7 +315,10 @@ unsigned pinhole_grid(const TraceParams& p, int n_cu)
     const size_t dyn = dyn_lds(p);
     const uint64_t slots_per_block = (uint64_t)kPinThreads * kR;
     const uint64_t want = ((uint64_t)p.cell_count * p.units_per_cell + slots_per_block - 1) / slots_per_block;
-    const uint64_t cap = (uint64_t)n_cu * (stream_mode(p) ? pinhole_blocks_per_cu<true>(dyn) : pinhole_blocks_per_cu<false>(dyn));
+    const bool cx = p.sc.n_cx > 0;
+    const int occ = stream_mode(p) ? (cx ? pinhole_blocks_per_cu<true, true>(dyn) : pinhole_blocks_per_cu<true, false>(dyn))
+                                   : (cx ? pinhole_blocks_per_cu<false, true>(dyn) : pinhole_blocks_per_cu<false, false>(dyn));
+    const uint64_t cap = (uint64_t)n_cu * occ;
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     return blocks ? blocks : 1;
 }
@@ -317,25 +332,31 @@ size_t pinhole_secq_bytes(const TraceParams& p, int n_cu)
 
 size_t pinhole_table_bytes(const TraceParams& p) { return stream_mode(p) ? (size_t)p.sc.n_sph_pad * sizeof(float4) : 0; }
 
-hipError_t launch_pinhole(const TraceParams& p, int n_cu, hipStream_t stream)
+template <bool CX>
+static hipError_t launch_pinhole_t(const TraceParams& p, int n_cu, hipStream_t stream)
 {
     const unsigned grid = pinhole_grid(p, n_cu);
     if (stream_mode(p)) {
         hipLaunchKernelGGL(pinhole_table_kernel, dim3((p.sc.n_sph_pad + 255) / 256), dim3(256), 0, stream, p, p.prim_table);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((pinhole_kernel<kR, true>), dim3(grid), dim3(kPinThreads), 0, stream, p);
+        hipLaunchKernelGGL((pinhole_kernel<kR, true, CX>), dim3(grid), dim3(kPinThreads), 0, stream, p);
         return hipGetLastError();
     }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)pinhole_kernel<kR, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)pinhole_kernel<kR, false, CX>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(kTileSpheres * sizeof(float4) * 2));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((pinhole_kernel<kR, false>), dim3(grid), dim3(kPinThreads), dyn_lds(p), stream, p);
+    hipLaunchKernelGGL((pinhole_kernel<kR, false, CX>), dim3(grid), dim3(kPinThreads), dyn_lds(p), stream, p);
     return hipGetLastError();
+}
+
+hipError_t launch_pinhole(const TraceParams& p, int n_cu, hipStream_t stream)
+{
+    return p.sc.n_cx > 0 ? launch_pinhole_t<true>(p, n_cu, stream) : launch_pinhole_t<false>(p, n_cu, stream);
 }
 
 }  // namespace rt

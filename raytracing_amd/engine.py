@@ -65,6 +65,28 @@ def plane(position, normal, material_kind, material_param=0.0, rotation_y_deg=0.
     return o
 
 
+def shape_object(shape, shape_param, position, material_kind, material_param=0.0, rotation_y_deg=0.0):
+    """Any ShapeConfig arm (shape_config.rs:9-51) as one RtObject; shape_param as documented in include/rt_hip.h."""
+    o = np.zeros((), abi.OBJECT_DTYPE)
+    o["shape"] = shape
+    o["material_kind"] = material_kind
+    o["material_param"] = material_param
+    o["rotation_y_deg"] = rotation_y_deg
+    o["position"] = position
+    sp = list(shape_param) + [0.0] * (4 - len(shape_param))
+    o["shape_param"] = sp
+    return o
+
+
+def tree_object(root_index, position, material_kind, material_param=0.0, rotation_y_deg=0.0):
+    """Union/Intersection/Difference tree: the root node index travels as the bits of shape_param[0]."""
+    o = shape_object(abi.RT_SHAPE_TREE, (0.0,), position, material_kind, material_param, rotation_y_deg)
+    sp = np.zeros(4, np.float32)
+    sp.view(np.uint32)[0] = root_index
+    o["shape_param"] = sp
+    return o
+
+
 def make_rays(origins, directions, current_ior=1.0):
     origins = np.asarray(origins, np.float32).reshape(-1, 3)
     rays = np.zeros(len(origins), abi.RAY_DTYPE)
@@ -77,11 +99,13 @@ def make_rays(origins, directions, current_ior=1.0):
 class Scene:
     """`Scene { objects, rays }` (scene.rs:28-31) with the object list resident in HBM."""
 
-    def __init__(self, objects, rays=None):
+    def __init__(self, objects, rays=None, nodes=None):
         self.objects = np.ascontiguousarray(np.asarray(objects, dtype=abi.OBJECT_DTYPE).reshape(-1))
         self.rays = np.zeros(0, abi.RAY_DTYPE) if rays is None else np.ascontiguousarray(rays, dtype=abi.RAY_DTYPE)
+        self.nodes = np.zeros(0, abi.NODE_DTYPE) if nodes is None else np.ascontiguousarray(nodes, dtype=abi.NODE_DTYPE)
         self._h = C.c_void_p()
-        check(lib().rt_hip_scene_create(abi.ptr(self.objects) if len(self.objects) else None, len(self.objects), C.byref(self._h)))
+        check(lib().rt_hip_scene_create_ex(abi.ptr(self.objects) if len(self.objects) else None, len(self.objects),
+                                           abi.ptr(self.nodes) if len(self.nodes) else None, len(self.nodes), C.byref(self._h)))
 
     def close(self):
         if self._h:

@@ -17,7 +17,7 @@ from oracle import binding as ob  # noqa: E402
 from raytracing_amd import synth  # noqa: E402
 from raytracing_amd.config import SimulationConfig  # noqa: E402
 
-from helpers import random_rays, random_scene  # noqa: E402
+from helpers import TEMPLATE_LIKE_TOML, random_rays, random_scene  # noqa: E402
 
 
 def main():
@@ -39,6 +39,14 @@ def main():
     c2 = synth.config_c2(48, 27)
     fb, fid, ft, seg, tot = ob.OracleScene(c2["objects"]).render(c2["gen"], 4, c2["infinity_distance"], c2["max_bounces"], seed=c2["seed"])
     np.savez(os.path.join(HERE, "c2_48x27_4spp.npz"), fb=fb, first_id=fid, first_t=ft, seg_count=seg, total=np.int64(tot))
+    # every ShapeConfig arm (template.toml's object set + Cone + CSG trees + rotated Sphere / Plane)
+    cfg = SimulationConfig.from_toml_str(TEMPLATE_LIKE_TOML)
+    objs, nodes = cfg.scene.object_and_node_lists()
+    rays = cfg.scene.ray_list()
+    st = cfg.simulation_settings
+    pts, npts, recs, tot = ob.OracleScene(objs, nodes).simulate(rays, st.infinity_distance, st.max_bounces, seed=3)
+    np.savez_compressed(os.path.join(HERE, "allshapes_paths.npz"), objects=objs, nodes=nodes, rays=rays, points=pts, n_points=npts,
+                        records=recs, total=np.int64(tot))
     print("golden vectors written")
 
 

@@ -73,12 +73,28 @@ def test_empty_scene_lists_default():
     assert len(cfg.scene.object_list()) == 0 and len(cfg.scene.ray_list()) == 0
 
 
-def test_shapes_not_on_gpu_path_are_reported():
-    cfg = SimulationConfig.from_toml_str(BASE + """
+def test_every_shape_arm_maps_to_the_abi():
+    """shape_config.rs:9-51: all ten ShapeConfig arms, including nested Union / Intersection / Difference trees."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from helpers import TEMPLATE_LIKE_TOML
+
+    cfg = SimulationConfig.from_toml_str(TEMPLATE_LIKE_TOML)
+    objs, nodes = cfg.scene.object_and_node_lists()
+    assert objs["shape"][:10].tolist() == [abi.RT_SHAPE_BOX, abi.RT_SHAPE_CYLINDER, abi.RT_SHAPE_WEDGE, abi.RT_SHAPE_LENS, abi.RT_SHAPE_PLANE,
+                                           abi.RT_SHAPE_CONE, abi.RT_SHAPE_TREE, abi.RT_SHAPE_TREE, abi.RT_SHAPE_SPHERE, abi.RT_SHAPE_PLANE]
+    assert np.array_equal(objs["shape_param"][2], np.float32([10, 8, 4, 15]))  # Wedge: size + angle_deg
+    assert np.array_equal(objs["shape_param"][3], np.float32([2, 18, 20, -20]))  # Lens: thickness, diameter, r1, r2
+    assert objs["rotation_y_deg"][0] == np.float32(25.0) and objs["rotation_y_deg"][2] == np.float32(-90.0)
+    # post-order node list: Difference(Sphere, Box) then Union(Sphere, Intersection(Cylinder, Sphere))
+    assert nodes["shape"].tolist() == [abi.RT_SHAPE_SPHERE, abi.RT_SHAPE_BOX, abi.RT_SHAPE_DIFFERENCE, abi.RT_SHAPE_SPHERE, abi.RT_SHAPE_CYLINDER,
+                                       abi.RT_SHAPE_SPHERE, abi.RT_SHAPE_INTERSECTION, abi.RT_SHAPE_UNION]
+    assert (nodes["a"][2], nodes["b"][2]) == (0, 1) and (nodes["a"][7], nodes["b"][7]) == (3, 6) and (nodes["a"][6], nodes["b"][6]) == (4, 5)
+    assert objs["shape_param"][6].view(np.uint32)[0] == 2 and objs["shape_param"][7].view(np.uint32)[0] == 7  # root indices
+    with pytest.raises(ConfigError, match="unknown shape"):
+        SimulationConfig.from_toml_str(BASE + """
 [[scene.objects]]
-shape = { type = "Box", size = [1.0, 1.0, 1.0] }
+shape = { type = "Torus", radius = 1.0 }
 material = { type = "Mirror" }
 transform = { position = [0.0, 0.0, 0.0], rotation_y_deg = 0.0 }
-""")
-    with pytest.raises(NotImplementedError, match="Box"):
-        cfg.scene.object_list()
+""").scene.object_list()
