@@ -357,3 +357,40 @@ def test_gpu_matches_golden_allshapes(engine):
     pts, npts, recs = sc.simulate_rays_raw(SimulationSettingsConfig(50.0, 10), rays=g["rays"], seed=3)
     assert np.array_equal(npts, g["n_points"]) and same(pts, g["points"])
     assert_records_equal(recs, g["records"], "allshapes golden")
+
+
+@pytest.mark.parametrize("spp,max_b,w,h", [(1, 1, 40, 30), (5, 2, 33, 17), (13, 8, 24, 24), (8, 3, 1, 1), (17, 12, 2, 70)])
+def test_render_ragged_sample_blocks_and_depths(engine, spp, max_b, w, h):
+    """spp not a multiple of the 8-sample work unit, depth 1 (no continuing rays), single-cell and skinny grids; planes and
+    HalfMirrors in the scene; strided cell ranges.  Pinhole kernel and general kernel against the oracle."""
+    objs = random_scene(150, 2, seed=spp * 7 + max_b, extent=(25.0, 15.0, 25.0))
+    st = SimulationSettingsConfig(35.0, max_b)
+    sc = engine.Scene(objs)
+    osc = ob.OracleScene(objs)
+    gens = [projector((0.0, 1.0, -60.0), (-30.0, -18.0, -25.0), (60.0, 0.0, 0.0), (0.0, 36.0, 0.0), w, h, 1.0),
+            parallel_grid((-28, -16, -50), (56, 0, 0), (0, 32, 0), w, h, (0.03, -0.02, 1.0), 1.0)]
+    n = w * h
+    for gen in gens:
+        for begin, step in ((0, 1), (n // 3, 2)):
+            count = (n - begin + step - 1) // step
+            got = sc.render(gen, spp, st, seed=77, cell_begin=begin, cell_count=count, cell_step=step)
+            want = osc.render(gen, spp, 35.0, max_b, seed=77, cell_begin=begin, cell_count=count, cell_step=step, threads=4)
+            for a, b in zip(got[:4], want[:4]):
+                assert np.array_equal(a, b)
+            assert got[4] == want[4]
+
+
+def test_simulate_many_rays_throughput_path(engine):
+    """2 x 10^5 explicit rays through the C2 scene: the general kernel with polyline output, sampled against the oracle."""
+    c2 = synth.config_c2(500, 400)
+    rays = ob.generate_rays(c2["gen"])
+    sc = engine.Scene(c2["objects"])
+    st = SimulationSettingsConfig(c2["infinity_distance"], c2["max_bounces"])
+    pts, npts, recs = sc.simulate_rays_raw(st, rays=rays, seed=5)
+    idx = np.random.default_rng(1).choice(len(rays), 3000, replace=False)
+    opts, onpts, orecs, _ = ob.OracleScene(c2["objects"]).simulate(rays[idx], c2["infinity_distance"], c2["max_bounces"], seed=5)
+    # ray ids differ (sub-batch), which only matters after a HalfMirror hit: compare rays that never met one
+    mats = c2["objects"]["material_kind"]
+    clean = np.array([not np.any(mats[orecs["obj_id"][k][orecs["obj_id"][k] >= 0]] == abi.RT_MAT_HALF_MIRROR) for k in range(len(idx))])
+    assert clean.sum() > 2500
+    assert np.array_equal(npts[idx][clean], onpts[clean]) and np.array_equal(pts[idx][clean], opts[clean])
