@@ -128,11 +128,12 @@ __device__ __forceinline__ void confirm_batch(WaveLds<R>& w, const DevScene& sc,
 }
 
 template <int R>
-__device__ __forceinline__ void push_candidates(WaveLds<R>& w, const DevScene& sc, unsigned long long mask, unsigned slot_base,
+__device__ __forceinline__ void push_candidates(WaveLds<R>& w, const DevScene& sc, unsigned long long mask, bool mine, unsigned slot_base,
                                                 unsigned j, unsigned& head, unsigned& tail, unsigned lane)
 {
+    // `mine` is this lane's bit of `mask` (the compare result itself), so the branch below is a plain exec = mask
     unsigned pos = tail + mbcnt64(mask);
-    if ((mask >> lane) & 1ull) w.queue[pos & (kQueueCap - 1)] = (j << 8) | (slot_base + lane);
+    if (mine) w.queue[pos & (kQueueCap - 1)] = (j << 8) | (slot_base + lane);
     tail += (unsigned)__builtin_popcountll(mask);
     if (tail - head >= 64u) {
         wave_lds_sync();
@@ -214,6 +215,7 @@ __device__ __forceinline__ void scan_step(const float4 (&sp)[kUnroll], unsigned 
                                           const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane)
 {
     unsigned long long mk[kUnroll][R];
+    bool ps[kUnroll][R];
     unsigned long long any = 0;
     if (FLAVOR == 1) {
         // stage-wise so the kUnroll*R dot products are independent chains (the scan is issue-bound, not latency-bound)
@@ -234,7 +236,8 @@ __device__ __forceinline__ void scan_step(const float4 (&sp)[kUnroll], unsigned 
         for (int u = 0; u < kUnroll; ++u)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                mk[u][r] = __ballot(__builtin_fabsf(h[u][r]) >= sp[u].w);
+                ps[u][r] = __builtin_fabsf(h[u][r]) >= sp[u].w;
+                mk[u][r] = __ballot(ps[u][r]);
                 any |= mk[u][r];
             }
     } else {
@@ -256,6 +259,7 @@ __device__ __forceinline__ void scan_step(const float4 (&sp)[kUnroll], unsigned 
                     float disc = half_b * half_b - c.a[r] * cc;
                     pass = c.live[r] && (jg + u < sc.n_sph) && !(disc < 0.0f);
                 }
+                ps[u][r] = pass;
                 mk[u][r] = __ballot(pass);
                 any |= mk[u][r];
             }
@@ -266,7 +270,7 @@ __device__ __forceinline__ void scan_step(const float4 (&sp)[kUnroll], unsigned 
         for (int u = 0; u < kUnroll; ++u) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (mk[u][r]) push_candidates<R>(w, sc, mk[u][r], r * 64, jg + u, head, tail, lane);
+                if (mk[u][r]) push_candidates<R>(w, sc, mk[u][r], ps[u][r], r * 64, jg + u, head, tail, lane);
             }
         }
     }
