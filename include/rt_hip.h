@@ -50,6 +50,8 @@ extern "C" {
 #define RT_SHAPE_LENS 6u     /* thickness, diameter, r1, r2                     -> (surface & surface) & cylinder  */
 #define RT_SHAPE_TREE 7u     /* Union/Intersection/Difference tree; the bits of shape_param[0] are the uint32 index of
                                 the root RtShapeNode (rt_hip_scene_create_ex) */
+#define RT_SHAPE_MESH 8u     /* triangle mesh — NO reference counterpart (BASELINE.json configs[2]); the bits of
+                                shape_param[0] are the uint32 index into RtSceneDesc.meshes.  Semantics: DESIGN.md §4.9 */
 /* operator codes, RtShapeNode only (shape_config.rs:39-50) */
 #define RT_SHAPE_UNION 16u
 #define RT_SHAPE_INTERSECTION 17u
@@ -76,6 +78,24 @@ typedef struct RtShapeNode {
     uint32_t b;
     float shape_param[4];
 } RtShapeNode; /* 28 bytes */
+
+/* Indexed triangle mesh in the object's local space (extension, see RT_SHAPE_MESH). */
+typedef struct RtMesh {
+    const float* vertices;   /* [n_vertices][3] */
+    uint64_t n_vertices;
+    const uint32_t* indices; /* [n_triangles][3] */
+    uint64_t n_triangles;
+} RtMesh; /* 32 bytes */
+
+/* Everything a scene is made of, for rt_hip_scene_create_desc. */
+typedef struct RtSceneDesc {
+    const RtObject* objects;
+    uint64_t n_objects;
+    const RtShapeNode* nodes; /* may be NULL when n_nodes == 0 */
+    uint64_t n_nodes;
+    const RtMesh* meshes;     /* may be NULL when n_meshes == 0 */
+    uint64_t n_meshes;
+} RtSceneDesc; /* 48 bytes */
 
 /* Ray (scene.rs:110-115), 28 bytes. Direction is used as given (the reference normalises when it
  * builds rays from config: ray_config.rs:16, scene_config.rs:72,103). */
@@ -135,6 +155,8 @@ int rt_hip_scene_create(const RtObject* objects, uint64_t n_objects, rt_scene** 
 /* Same, with the node array that RT_SHAPE_TREE objects index (nodes may be NULL when n_nodes == 0). */
 int rt_hip_scene_create_ex(const RtObject* objects, uint64_t n_objects, const RtShapeNode* nodes, uint64_t n_nodes,
                            rt_scene** out_scene);
+/* Same, everything through one descriptor (adds triangle meshes; a BVH per mesh is built here on the host). */
+int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene);
 void rt_hip_scene_destroy(rt_scene* scene);
 
 /* ---- the hot call: Scene::simulate_rays (scene.rs:39-106) ----

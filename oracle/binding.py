@@ -24,6 +24,8 @@ def lib():
         L.orc_scene_create.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_scene_create_ex.restype = C.c_void_p
         L.orc_scene_create_ex.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.orc_scene_create_desc.restype = C.c_void_p
+        L.orc_scene_create_desc.argtypes = [C.POINTER(abi.RtSceneDesc)]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_simulate.restype = C.c_uint64
         L.orc_simulate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, abi.RtSettings, C.c_uint64, C.c_uint64,
@@ -51,11 +53,12 @@ def lib():
 
 
 class OracleScene:
-    def __init__(self, objects, nodes=None):
+    def __init__(self, objects, nodes=None, meshes=None):
         self.objects = np.ascontiguousarray(objects, dtype=abi.OBJECT_DTYPE)
         self.nodes = np.zeros(0, abi.NODE_DTYPE) if nodes is None else np.ascontiguousarray(nodes, dtype=abi.NODE_DTYPE)
-        self._h = lib().orc_scene_create_ex(abi.ptr(self.objects), len(self.objects), abi.ptr(self.nodes) if len(self.nodes) else None,
-                                            len(self.nodes))
+        desc, keep = abi.scene_desc(self.objects, self.nodes, list(meshes) if meshes else [])
+        self._h = lib().orc_scene_create_desc(C.byref(desc))
+        del keep
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -342,6 +342,57 @@ struct InfConePrim : Prim {  // infinite_cone.rs:14-86
     }
 };
 
+// Triangle mesh — no reference counterpart; restates DESIGN.md §4.9.  intersect_all returns the single
+// nearest triangle hit in (t_min, t_max) (ties: lowest triangle index), found here by brute force over every triangle;
+// the GPU path finds the same hit through a BVH.  Moller-Trumbore in strict f32, plus the padded-box rule below.
+inline V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+struct MeshPrim : Prim {
+    std::vector<V3> v0, e1, e2;
+    // the hit point must lie in the triangle's padded box: min / max over v0, v0+e1, v0+e2, grown by 1e-5 (|.|max + extent) + 1e-6
+    static bool box_holds(float a, float ea, float eb, float p)
+    {
+        float b = a + ea, c = a + eb;
+        float lo = std::fmin(a, std::fmin(b, c)), hi = std::fmax(a, std::fmax(b, c));
+        float mag = std::fmax(std::fabs(lo), std::fabs(hi));
+        float pad = 1e-5f * (mag + (hi - lo)) + 1e-6f;
+        return p >= lo - pad && p <= hi + pad;
+    }
+    void intersect_all(const Ray& ray, float t_min, float t_max, std::vector<Hit>& out) const override
+    {
+        float best = std::numeric_limits<float>::infinity();
+        long best_k = -1;
+        for (size_t k = 0; k < v0.size(); ++k) {
+            V3 pvec = cross(ray.direction, e2[k]);
+            float det = dot(e1[k], pvec);
+            if (std::fabs(det) < 1e-12f) continue;
+            float inv = 1.0f / det;
+            V3 tvec = ray.origin - v0[k];
+            float u = dot(tvec, pvec) * inv;
+            if (u < 0.0f || u > 1.0f) continue;
+            V3 qvec = cross(tvec, e1[k]);
+            float v = dot(ray.direction, qvec) * inv;
+            if (v < 0.0f || u + v > 1.0f) continue;
+            float t = dot(e2[k], qvec) * inv;
+            if (!(t > t_min && t < t_max)) continue;
+            V3 p = ray.origin + t * ray.direction;
+            if (!(box_holds(v0[k].x, e1[k].x, e2[k].x, p.x) && box_holds(v0[k].y, e1[k].y, e2[k].y, p.y) && box_holds(v0[k].z, e1[k].z, e2[k].z, p.z))) continue;
+            if (t < best) {
+                best = t;
+                best_k = (long)k;
+            }
+        }
+        if (best_k < 0) return;
+        V3 n = cross(e1[best_k], e2[best_k]);
+        bool front = dot(ray.direction, n) < 0.0f;
+        Hit h{};
+        h.t = best;
+        h.point = ray.origin + best * ray.direction;
+        h.normal = front ? n : -n;
+        h.front_face = front;
+        out.push_back(h);
+    }
+};
+
 struct CsgPrim : Prim {  // csg.rs:3-76
     std::unique_ptr<Prim> left, right;
     uint32_t op;  // RT_SHAPE_UNION / INTERSECTION / DIFFERENCE
@@ -484,7 +535,8 @@ struct Object {  // Transform(Box<primitive>) — transform.rs:4-17, object_conf
     std::shared_ptr<Prim> prim;  // shapes other than Sphere / Plane
 };
 
-Object build_object(const RtObject& o, const RtShapeNode* nodes = nullptr, uint64_t n_nodes = 0)
+Object build_object(const RtObject& o, const RtShapeNode* nodes = nullptr, uint64_t n_nodes = 0, const RtMesh* meshes = nullptr,
+                    uint64_t n_meshes = 0)
 {
     Object r{};
     r.shape = o.shape;
@@ -503,6 +555,21 @@ Object build_object(const RtObject& o, const RtShapeNode* nodes = nullptr, uint6
             uint32_t root;
             std::memcpy(&root, &o.shape_param[0], 4);
             p = build_node(nodes, n_nodes, root, 0);
+        } else if (o.shape == RT_SHAPE_MESH) {
+            uint32_t mi;
+            std::memcpy(&mi, &o.shape_param[0], 4);
+            if (mi < n_meshes) {
+                const RtMesh& m = meshes[mi];
+                auto mp = std::make_unique<MeshPrim>();
+                for (uint64_t k = 0; k < m.n_triangles; ++k) {
+                    auto vert = [&](uint32_t idx) { return v3(m.vertices[idx * 3 + 0], m.vertices[idx * 3 + 1], m.vertices[idx * 3 + 2]); };
+                    V3 a = vert(m.indices[k * 3 + 0]), b = vert(m.indices[k * 3 + 1]), c = vert(m.indices[k * 3 + 2]);
+                    mp->v0.push_back(a);
+                    mp->e1.push_back(b - a);
+                    mp->e2.push_back(c - a);
+                }
+                p = std::move(mp);
+            }
         } else {
             p = build_shape(o.shape, o.shape_param, nodes, n_nodes, 0);
         }
@@ -707,12 +774,18 @@ struct orc_scene {
     Scene sc;
 };
 
-orc_scene* orc_scene_create_ex(const RtObject* objects, uint64_t n, const RtShapeNode* nodes, uint64_t n_nodes)
+orc_scene* orc_scene_create_desc(const RtSceneDesc* d)
 {
     orc_scene* s = new orc_scene;
-    s->sc.objects.reserve(n);
-    for (uint64_t k = 0; k < n; ++k) s->sc.objects.push_back(build_object(objects[k], nodes, n_nodes));
+    s->sc.objects.reserve(d->n_objects);
+    for (uint64_t k = 0; k < d->n_objects; ++k)
+        s->sc.objects.push_back(build_object(d->objects[k], d->nodes, d->n_nodes, d->meshes, d->n_meshes));
     return s;
+}
+orc_scene* orc_scene_create_ex(const RtObject* objects, uint64_t n, const RtShapeNode* nodes, uint64_t n_nodes)
+{
+    RtSceneDesc d{objects, n, nodes, n_nodes, nullptr, 0};
+    return orc_scene_create_desc(&d);
 }
 orc_scene* orc_scene_create(const RtObject* objects, uint64_t n) { return orc_scene_create_ex(objects, n, nullptr, 0); }
 void orc_scene_destroy(orc_scene* s) { delete s; }

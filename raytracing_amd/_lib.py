@@ -18,6 +18,7 @@ EXPORTS = [
     "rt_hip_last_error",
     "rt_hip_scene_create",
     "rt_hip_scene_create_ex",
+    "rt_hip_scene_create_desc",
     "rt_hip_scene_destroy",
     "rt_hip_scene_counts",
     "rt_hip_simulate",
@@ -54,6 +55,8 @@ def lib():
     L.rt_hip_scene_create.restype = C.c_int
     L.rt_hip_scene_create_ex.argtypes = [vp, u64, vp, u64, C.POINTER(vp)]
     L.rt_hip_scene_create_ex.restype = C.c_int
+    L.rt_hip_scene_create_desc.argtypes = [C.POINTER(abi.RtSceneDesc), C.POINTER(vp)]
+    L.rt_hip_scene_create_desc.restype = C.c_int
     L.rt_hip_scene_destroy.argtypes = [vp]
     L.rt_hip_scene_destroy.restype = None
     L.rt_hip_scene_counts.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]

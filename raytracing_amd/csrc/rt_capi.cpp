@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "rt_host_bvh.h"
 #include "rt_host_shapes.h"
 #include "rt_internal.h"
 
@@ -232,7 +233,29 @@ int rt_hip_scene_create(const RtObject* objects, uint64_t n_objects, rt_scene** 
 int rt_hip_scene_create_ex(const RtObject* objects, uint64_t n_objects, const RtShapeNode* shape_nodes, uint64_t n_shape_nodes,
                            rt_scene** out_scene)
 {
+    RtSceneDesc d{objects, n_objects, shape_nodes, n_shape_nodes, nullptr, 0};
+    return rt_hip_scene_create_desc(&d, out_scene);
+}
+
+int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
+{
     std::lock_guard<std::mutex> lk(g_mu);
+    if (!desc) return fail(RT_ERR_INVALID, "null argument");
+    const RtObject* objects = desc->objects;
+    const uint64_t n_objects = desc->n_objects;
+    const RtShapeNode* shape_nodes = desc->nodes;
+    const uint64_t n_shape_nodes = desc->n_nodes;
+    if (!desc->meshes && desc->n_meshes) return fail(RT_ERR_INVALID, "null argument");
+    for (uint64_t mi = 0; mi < desc->n_meshes; ++mi) {
+        const RtMesh& m = desc->meshes[mi];
+        if ((!m.vertices && m.n_vertices) || (!m.indices && m.n_triangles)) return fail(RT_ERR_INVALID, "mesh " + std::to_string(mi) + ": null array");
+        if (m.n_triangles >= (1ull << 28)) return fail(RT_ERR_INVALID, "mesh " + std::to_string(mi) + ": too many triangles");
+        for (uint64_t k = 0; k < m.n_triangles * 3; ++k)
+            if (m.indices[k] >= m.n_vertices) return fail(RT_ERR_INVALID, "mesh " + std::to_string(mi) + ": vertex index out of range");
+    }
+    std::vector<rt::BvhNode> bvh_nodes;
+    std::vector<rt::TriDev> tris;
+    std::vector<uint32_t> mesh_roots(desc->n_meshes, rt::kNoMesh);
     if (!g_ctx.ready) return fail(RT_ERR_NOT_INIT, "rt_hip_init() has not been called");
     if (!out_scene || (!objects && n_objects) || (!shape_nodes && n_shape_nodes)) return fail(RT_ERR_INVALID, "null argument");
     if (n_objects >= (1ull << 23)) return fail(RT_ERR_INVALID, "too many objects (limit 2^23)");
@@ -259,7 +282,23 @@ int rt_hip_scene_create_ex(const RtObject* objects, uint64_t n_objects, const Rt
         if (!fast) {
             rt::host::Program pr;
             std::string err;
-            if (rt::host::emit_shape(o.shape, o.shape_param, shape_nodes, n_shape_nodes, pr, 0, 0, err) < 0)
+            uint32_t mesh_root = rt::kNoMesh;
+            if (o.shape == RT_SHAPE_MESH) {
+                uint32_t mi;
+                std::memcpy(&mi, &o.shape_param[0], 4);
+                if (mi >= desc->n_meshes) return fail(RT_ERR_INVALID, "object " + std::to_string(k) + ": mesh index out of range");
+                if (mesh_roots[mi] == rt::kNoMesh && desc->meshes[mi].n_triangles)
+                    mesh_roots[mi] = rt::host::build_mesh_bvh(desc->meshes[mi], bvh_nodes, tris);
+                mesh_root = mesh_roots[mi];
+                if (mesh_root == rt::kNoMesh) {  // empty mesh: NaN bounds fail every slab test (an inverted box would not:
+                    rt::BvhNode e{};             // min / max of the two plane distances re-orders it into all of space)
+                    const float nan = std::numeric_limits<float>::quiet_NaN();
+                    e.lo = make_float4(nan, nan, nan, 0.f);
+                    e.hi = make_float4(nan, nan, nan, 0.f);
+                    mesh_root = mesh_roots[mi] = (uint32_t)bvh_nodes.size();
+                    bvh_nodes.push_back(e);
+                }
+            } else if (rt::host::emit_shape(o.shape, o.shape_param, shape_nodes, n_shape_nodes, pr, 0, 0, err) < 0)
                 return fail(RT_ERR_INVALID, "object " + std::to_string(k) + ": " + err);
             if (pr.max_hits > rt::kCxMaxHits || pr.max_stack > rt::kCxStack)
                 return fail(RT_ERR_UNSUPPORTED, "object " + std::to_string(k) + ": shape tree needs " + std::to_string(pr.max_hits) +
@@ -269,6 +308,7 @@ int rt_hip_scene_create_ex(const RtObject* objects, uint64_t n_objects, const Rt
             co.first_node = (uint32_t)cx_nodes.size();
             co.n_nodes = (uint32_t)pr.nodes.size();
             co.obj_id = (int32_t)k;
+            co.mesh_root = mesh_root;
             rt::host::Mat4 m, mi;
             rt::host::object_matrices(o, m, mi);
             std::memcpy(co.m, m.c, sizeof co.m);
@@ -328,6 +368,8 @@ int rt_hip_scene_create_ex(const RtObject* objects, uint64_t n_objects, const Rt
     up(obj_shape, &d.obj_shape);
     up(cx_nodes, &d.cx_nodes);
     up(cx_objs, &d.cx_objs);
+    up(bvh_nodes, &d.bvh_nodes);
+    up(tris, &d.tris);
     if (e != hipSuccess) {
         free_scene(s);
         return fail_hip(e, "scene upload");

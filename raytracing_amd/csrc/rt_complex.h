@@ -213,11 +213,97 @@ __device__ __noinline__ int cx_combine(uint32_t op, const CxHit* L, int nl, cons
     return no;
 }
 
+__device__ __forceinline__ F3 cross(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+
+// One axis of a triangle's padded box: min / max over v0, v0+e1, v0+e2, grown by 1e-5 (|.|max + extent) + 1e-6.
+__device__ __forceinline__ bool tri_box_holds(float a, float e1, float e2, float p)
+{
+    const float b = a + e1, c = a + e2;
+    const float lo = __builtin_fminf(a, __builtin_fminf(b, c)), hi = __builtin_fmaxf(a, __builtin_fmaxf(b, c));
+    const float mag = __builtin_fmaxf(__builtin_fabsf(lo), __builtin_fabsf(hi));
+    const float pad = 1e-5f * (mag + (hi - lo)) + 1e-6f;
+    return p >= lo - pad && p <= hi + pad;
+}
+
+// Nearest triangle of a mesh in (0.001, +inf), ties to the lowest triangle index: Moller-Trumbore in
+// strict f32, and the hit point o + t d must lie in the triangle's padded box.  That last rule is what makes the BVH
+// exact: node boxes are unions of those triangle boxes (padded once more) and the slab test is widened past its own
+// rounding, so a node is skipped only when none of its triangles can pass; the result equals the oracle's brute-force
+// loop bit for bit.
+__device__ __noinline__ bool mesh_first_hit(const DevScene& sc, uint32_t root, F3 o, F3 d, CxHit& out)
+{
+    const float inf = __builtin_inff();
+    float best = inf;
+    uint32_t best_id = 0xffffffffu, best_k = 0;
+    const F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // o + t d is rounded relative to |o| as well as to the box: grow every box by 8 ulp of the origin
+    const F3 ro = f3(4.8e-7f * __builtin_fabsf(o.x), 4.8e-7f * __builtin_fabsf(o.y), 4.8e-7f * __builtin_fabsf(o.z));
+    uint32_t stack[kBvhStack];
+    int sp = 0;
+    stack[sp++] = root;
+    while (sp > 0) {
+        const uint32_t ni = stack[--sp];
+        const BvhNode n = sc.bvh_nodes[ni];
+        // slab test; fmin / fmax drop the NaN of 0 * inf (origin on a slab plane, zero direction component)
+        float t0 = ((n.lo.x - ro.x) - o.x) * inv.x, t1 = ((n.hi.x + ro.x) - o.x) * inv.x;
+        float tn = __builtin_fminf(t0, t1), tf = __builtin_fmaxf(t0, t1);
+        t0 = ((n.lo.y - ro.y) - o.y) * inv.y; t1 = ((n.hi.y + ro.y) - o.y) * inv.y;
+        tn = __builtin_fmaxf(tn, __builtin_fminf(t0, t1)); tf = __builtin_fminf(tf, __builtin_fmaxf(t0, t1));
+        t0 = ((n.lo.z - ro.z) - o.z) * inv.z; t1 = ((n.hi.z + ro.z) - o.z) * inv.z;
+        tn = __builtin_fmaxf(tn, __builtin_fminf(t0, t1)); tf = __builtin_fminf(tf, __builtin_fmaxf(t0, t1));
+        tn = tn - 1e-6f * __builtin_fabsf(tn) - 1e-7f;
+        tf = tf + 1e-6f * __builtin_fabsf(tf) + 1e-7f;
+        if (!(tn <= tf) || tf < 0.0f || tn > best) continue;
+        const uint32_t cnt = __float_as_uint(n.hi.w), first = __float_as_uint(n.lo.w);
+        if (cnt == 0) {
+            if (sp + 2 <= kBvhStack) {
+                stack[sp++] = first;
+                stack[sp++] = first + 1;
+            }
+            continue;
+        }
+        for (uint32_t k = first; k < first + cnt; ++k) {
+            const TriDev tr = sc.tris[k];
+            const F3 v0 = f3(tr.v0.x, tr.v0.y, tr.v0.z), e1 = f3(tr.e1.x, tr.e1.y, tr.e1.z), e2 = f3(tr.e2.x, tr.e2.y, tr.e2.z);
+            const F3 pvec = cross(d, e2);
+            const float det = dot(e1, pvec);
+            if (__builtin_fabsf(det) < 1e-12f) continue;
+            const float idet = 1.0f / det;
+            const F3 tvec = o - v0;
+            const float u = dot(tvec, pvec) * idet;
+            if (u < 0.0f || u > 1.0f) continue;
+            const F3 qvec = cross(tvec, e1);
+            const float v = dot(d, qvec) * idet;
+            if (v < 0.0f || u + v > 1.0f) continue;
+            const float t = dot(e2, qvec) * idet;
+            if (!(t > kTMin && t < inf)) continue;
+            const F3 p = o + t * d;
+            if (!(tri_box_holds(v0.x, e1.x, e2.x, p.x) && tri_box_holds(v0.y, e1.y, e2.y, p.y) && tri_box_holds(v0.z, e1.z, e2.z, p.z))) continue;
+            const uint32_t id = __float_as_uint(tr.v0.w);
+            if (t < best || (t == best && id < best_id)) {
+                best = t;
+                best_id = id;
+                best_k = k;
+            }
+        }
+    }
+    if (best_id == 0xffffffffu) return false;
+    const TriDev tr = sc.tris[best_k];
+    const F3 nrm = cross(f3(tr.e1.x, tr.e1.y, tr.e1.z), f3(tr.e2.x, tr.e2.y, tr.e2.z));
+    const bool front = dot(d, nrm) < 0.0f;
+    out.t = best;
+    out.p = o + best * d;
+    out.n = front ? nrm : -nrm;
+    out.ff = front ? 1u : 0u;
+    return true;
+}
+
 // hits.first() of Transform(object).intersect_all(ray, 0.001, +inf), still in the object's local space.
 __device__ __noinline__ bool cx_first_hit(const DevScene& sc, const CxObject& ob, F3 o, F3 d, CxHit& first)
 {
     const F3 lo = xf_point(ob.minv, o);
     const F3 ld = xf_vector(ob.minv, d);
+    if (ob.mesh_root != kNoMesh) return mesh_first_hit(sc, ob.mesh_root, lo, ld, first);
     CxHit st[kCxStack][kCxMaxHits];
     int cnt[kCxStack];
     int sp = 0;

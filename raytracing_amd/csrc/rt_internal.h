@@ -24,10 +24,23 @@ struct CxNode {
 struct CxObject {
     uint32_t first_node, n_nodes;
     int32_t obj_id;
-    uint32_t pad;
+    uint32_t mesh_root;  // root BvhNode of a triangle mesh object, kNoMesh otherwise
     float m[16];     // Transform.transform          (column-major, glam Mat4)
     float minv[16];  // Transform.inverse_transform
 };
+
+constexpr uint32_t kNoMesh = 0xffffffffu;
+// Triangle meshes (extension): one BVH per mesh, nodes and triangles of all meshes in two flat arrays.
+struct BvhNode {
+    float4 lo;  // padded box min; w bits = left child index (right = left + 1) for inner nodes, first triangle for leaves
+    float4 hi;  // padded box max; w bits = triangle count (0 = inner node)
+};
+struct TriDev {
+    float4 v0;  // w bits = triangle index in the caller's mesh (tie-break key)
+    float4 e1;  // v1 - v0 (f32)
+    float4 e2;  // v2 - v0 (f32)
+};
+constexpr int kBvhStack = 64;
 
 // Flattened scene as the kernels see it (all pointers are device memory).
 struct DevScene {
@@ -43,6 +56,8 @@ struct DevScene {
     const uint32_t* obj_shape;  // [n_obj]
     const CxNode* cx_nodes;     // node programs of the complex objects
     const CxObject* cx_objs;    // [n_cx]
+    const BvhNode* bvh_nodes;   // all meshes
+    const TriDev* tris;         // all meshes, BVH leaf order
     uint32_t n_cx;
     uint32_t n_sph, n_sph_pad, n_pl, n_obj;
     float c2max;  // >= max_j (|p_j|^2 + r_j^2), rounded up: magnitude bound used by the cull margin

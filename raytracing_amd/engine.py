@@ -87,6 +87,13 @@ def tree_object(root_index, position, material_kind, material_param=0.0, rotatio
     return o
 
 
+def mesh_object(mesh_index, position, material_kind, material_param=0.0, rotation_y_deg=0.0):
+    """Triangle-mesh object (extension): the mesh index travels as the bits of shape_param[0]."""
+    o = tree_object(mesh_index, position, material_kind, material_param, rotation_y_deg)
+    o["shape"] = abi.RT_SHAPE_MESH
+    return o
+
+
 def make_rays(origins, directions, current_ior=1.0):
     origins = np.asarray(origins, np.float32).reshape(-1, 3)
     rays = np.zeros(len(origins), abi.RAY_DTYPE)
@@ -99,13 +106,15 @@ def make_rays(origins, directions, current_ior=1.0):
 class Scene:
     """`Scene { objects, rays }` (scene.rs:28-31) with the object list resident in HBM."""
 
-    def __init__(self, objects, rays=None, nodes=None):
+    def __init__(self, objects, rays=None, nodes=None, meshes=None):
         self.objects = np.ascontiguousarray(np.asarray(objects, dtype=abi.OBJECT_DTYPE).reshape(-1))
         self.rays = np.zeros(0, abi.RAY_DTYPE) if rays is None else np.ascontiguousarray(rays, dtype=abi.RAY_DTYPE)
         self.nodes = np.zeros(0, abi.NODE_DTYPE) if nodes is None else np.ascontiguousarray(nodes, dtype=abi.NODE_DTYPE)
+        self.meshes = list(meshes) if meshes else []
         self._h = C.c_void_p()
-        check(lib().rt_hip_scene_create_ex(abi.ptr(self.objects) if len(self.objects) else None, len(self.objects),
-                                           abi.ptr(self.nodes) if len(self.nodes) else None, len(self.nodes), C.byref(self._h)))
+        desc, keep = abi.scene_desc(self.objects, self.nodes, self.meshes)
+        check(lib().rt_hip_scene_create_desc(C.byref(desc), C.byref(self._h)))
+        del keep
 
     def close(self):
         if self._h:

@@ -52,3 +52,31 @@ def config_c4(count_u=3840, count_v=2160):
     objs = sphere_scene(10000, (150.0, 60.0, 150.0))
     gen = projector((0.0, 0.0, -360.0), (-192.0, -108.0, -180.0), (384.0, 0.0, 0.0), (0.0, 216.0, 0.0), count_u, count_v)
     return dict(objects=objs, gen=gen, spp=1024, max_bounces=8, infinity_distance=50.0, seed=0xC0FFEE, name="C4")
+
+
+def heightfield_mesh(nx, nz, extent=(60.0, 60.0), amplitude=6.0, seed=0xC0FFEE):
+    """(vertices [n,3] f32, indices [m,3] u32): a bumpy nx x nz grid in the XZ plane, 2*nx*nz triangles."""
+    ex, ez = extent
+    xs = np.linspace(-ex, ex, nx + 1, dtype=np.float32)
+    zs = np.linspace(-ez, ez, nz + 1, dtype=np.float32)
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    noise = philox_u01(seed, (nx + 1) * (nz + 1), 7).reshape(nx + 1, nz + 1)
+    Y = (np.float32(amplitude) * (np.sin(X * np.float32(0.21)) * np.cos(Z * np.float32(0.17)) + np.float32(0.3) * (noise - np.float32(0.5)))).astype(np.float32)
+    v = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(np.float32)
+    i, j = np.meshgrid(np.arange(nx), np.arange(nz), indexing="ij")
+    a = (i * (nz + 1) + j).ravel()
+    b, c, d = a + (nz + 1), a + 1, a + (nz + 1) + 1
+    idx = np.concatenate([np.stack([a, b, c], 1), np.stack([c, b, d], 1)], 0).astype(np.uint32)
+    return v, idx
+
+
+def config_c3(count_u=1920, count_v=1080, nx=224, nz=224):
+    """BASELINE.json configs[2]: synthetic ~100k-triangle mesh (BVH path), 1920x1080, 256 spp.  No reference counterpart."""
+    from .engine import mesh_object
+
+    v, idx = heightfield_mesh(nx, nz)
+    objs = np.array([mesh_object(0, (0.0, -10.0, 0.0), abi.RT_MAT_MIRROR, 0.0, rotation_y_deg=15.0)] + list(sphere_scene(50, (40.0, 8.0, 40.0), seed=3)),
+                    dtype=abi.OBJECT_DTYPE)
+    objs["position"][1:, 1] += np.float32(6.0)
+    gen = projector((0.0, 40.0, -120.0), (-64.0, -40.0, -40.0), (128.0, 0.0, 0.0), (0.0, 72.0, 0.0), count_u, count_v)
+    return dict(objects=objs, meshes=[(v, idx)], gen=gen, spp=256, max_bounces=8, infinity_distance=50.0, seed=0xC0FFEE, name="C3")

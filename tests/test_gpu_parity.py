@@ -394,3 +394,65 @@ def test_simulate_many_rays_throughput_path(engine):
     clean = np.array([not np.any(mats[orecs["obj_id"][k][orecs["obj_id"][k] >= 0]] == abi.RT_MAT_HALF_MIRROR) for k in range(len(idx))])
     assert clean.sum() > 2500
     assert np.array_equal(npts[idx][clean], onpts[clean]) and np.array_equal(pts[idx][clean], opts[clean])
+
+
+def _soup(n_tris, seed, extent=15.0, size=3.0):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-extent, extent, size=(n_tris, 1, 3))
+    v = (c + rng.normal(size=(n_tris, 3, 3)) * size).astype(np.float32).reshape(-1, 3)
+    idx = np.arange(n_tris * 3, dtype=np.uint32).reshape(-1, 3)
+    return v, idx
+
+
+def test_triangle_meshes_bvh_equals_brute_force(engine):
+    """Extension (no reference counterpart): the BVH traversal must return exactly the brute-force nearest triangle
+    (t bit-exact, ties to the lowest index) for a random triangle soup, a shared-vertex heightfield and an empty mesh,
+    under rotated transforms, mixed with spheres and planes."""
+    from raytracing_amd.engine import mesh_object
+
+    soup = _soup(3000, 1)
+    hf = synth.heightfield_mesh(40, 40, extent=(20.0, 20.0), amplitude=3.0)
+    dup = (np.array([[-5, -5, 0], [5, -5, 0], [0, 5, 0]] * 2, np.float32), np.array([[0, 1, 2], [3, 4, 5]], np.uint32))  # coincident pair
+    empty = (np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32))
+    objs = list(random_scene(80, 1, seed=5))
+    objs.insert(3, mesh_object(0, (0, 0, 0), abi.RT_MAT_GLASS, 1.4, rotation_y_deg=20.0))
+    objs.insert(10, mesh_object(1, (0, -12, 0), abi.RT_MAT_MIRROR, 0.0, rotation_y_deg=-35.0))
+    objs.insert(20, mesh_object(2, (0, 0, 22), abi.RT_MAT_HALF_MIRROR, 0.5))
+    objs.append(mesh_object(3, (0, 0, 0), abi.RT_MAT_MIRROR))
+    objs.append(mesh_object(1, (30, 5, 0), abi.RT_MAT_GLASS, 1.2, rotation_y_deg=90.0))  # a second instance of mesh 1
+    objs = np.array(objs, dtype=abi.OBJECT_DTYPE)
+    meshes = [soup, hf, dup, empty]
+    rays = random_rays(8000, seed=17, extent=(28.0, 14.0, 28.0))
+    sc = engine.Scene(objs, meshes=meshes)
+    st = SimulationSettingsConfig(50.0, 6)
+    pts, npts, recs = sc.simulate_rays_raw(st, rays=rays, seed=2)
+    opts, onpts, orecs, _ = ob.OracleScene(objs, meshes=meshes).simulate(rays, 50.0, 6, seed=2)
+    assert np.array_equal(npts, onpts)
+    assert_records_equal(recs, orecs, "meshes")
+    assert same(pts, opts)
+    # grazing rays: nearly in the plane of a flat sheet, where Moller-Trumbore is worst conditioned
+    flat = synth.heightfield_mesh(24, 24, extent=(20.0, 20.0), amplitude=0.0)
+    rng = np.random.default_rng(3)
+    o = np.stack([rng.uniform(-30, 30, 4000), rng.uniform(-1e-3, 1e-3, 4000), rng.uniform(-30, 30, 4000)], 1)
+    tgt = np.stack([rng.uniform(-20, 20, 4000), rng.uniform(-1e-4, 1e-4, 4000), rng.uniform(-20, 20, 4000)], 1)
+    dirs = tgt - o
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    graze = make_rays(o, dirs)
+    gobjs = np.array([mesh_object(0, (0, 0, 0), abi.RT_MAT_MIRROR, rotation_y_deg=33.0)], dtype=abi.OBJECT_DTYPE)
+    gp, gn, gr = engine.Scene(gobjs, meshes=[flat]).simulate_rays_raw(SimulationSettingsConfig(50.0, 3), rays=graze, seed=1)
+    wp, wn, wr, _ = ob.OracleScene(gobjs, meshes=[flat]).simulate(graze, 50.0, 3, seed=1)
+    assert np.array_equal(gn, wn) and same(gp, wp)
+    assert_records_equal(gr, wr, "grazing")
+    assert (gn > 2).sum() > 500
+    hit = set(np.unique(recs["obj_id"][recs["obj_id"] >= 0]).tolist())
+    mesh_ids = set(np.flatnonzero(objs["shape"] == abi.RT_SHAPE_MESH).tolist())
+    assert len(hit & mesh_ids) >= 3
+    # render loop on the reduced C3 scene (pinhole kernel + mesh)
+    c3 = synth.config_c3(48, 27, nx=32, nz=32)
+    sc3 = engine.Scene(c3["objects"], meshes=c3["meshes"])
+    st3 = SimulationSettingsConfig(c3["infinity_distance"], c3["max_bounces"])
+    got = sc3.render(c3["gen"], 3, st3, seed=1)
+    want = ob.OracleScene(c3["objects"], meshes=c3["meshes"]).render(c3["gen"], 3, c3["infinity_distance"], c3["max_bounces"], seed=1, threads=4)
+    for a, b in zip(got[:4], want[:4]):
+        assert same(a, b)
+    assert got[4] == want[4] and (got[1] == 0).sum() > 50  # the mesh (object 0) is what most primary rays hit

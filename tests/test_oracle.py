@@ -277,3 +277,32 @@ def test_oracle_matches_golden_allshapes():
     pts, npts, recs, tot = ob.OracleScene(objs, nodes).simulate(cfg.scene.ray_list(), st.infinity_distance, st.max_bounces, seed=3)
     assert np.array_equal(npts, g["n_points"]) and tot == int(g["total"]) and same(pts, g["points"])
     assert_records_equal(recs, g["records"], "allshapes")
+
+
+def test_mesh_known_answers():
+    """Triangle meshes are an extension (no reference counterpart): nearest Moller-Trumbore hit, ties to
+    the lowest triangle index, geometric normal flipped against the ray, empty meshes never hit."""
+    from raytracing_amd.engine import mesh_object, make_rays
+
+    tri = (np.array([[-5, -5, 0], [5, -5, 0], [0, 5, 0]], np.float32), np.array([[0, 1, 2]], np.uint32))
+    two = (np.array([[-5, -5, 0], [5, -5, 0], [0, 5, 0], [-5, -5, 2], [5, -5, 2], [0, 5, 2]], np.float32), np.array([[3, 4, 5], [0, 1, 2]], np.uint32))
+    empty = (np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32))
+    objs = np.array([mesh_object(0, (0, 0, 5), abi.RT_MAT_MIRROR), mesh_object(2, (0, 0, 1), abi.RT_MAT_MIRROR),
+                     mesh_object(1, (20, 0, 5), abi.RT_MAT_MIRROR)], dtype=abi.OBJECT_DTYPE)
+    rays = make_rays([(0, 0, 0), (0, 0, 10), (20, 0, 0), (20, 0, 10), (0, 40, 0), (5.5, -5, 0)],
+                     [(0, 0, 1), (0, 0, -1), (0, 0, 1), (0, 0, -1), (0, 0, 1), (0, 0, 1)])
+    pts, npts, recs, _ = ob.OracleScene(objs, meshes=[tri, two, empty]).simulate(rays, 20.0, 1, seed=0)
+    recs = recs.reshape(len(rays), -1)[:, 0]
+    assert recs["obj_id"].tolist() == [0, 0, 2, 2, -1, -1]
+    assert recs["t"][:4].tolist() == [5.0, 5.0, 5.0, 3.0]                  # mesh `two`: z=0 sheet from below, z=2 sheet from above
+    assert recs["normal"][0].tolist() == [0.0, 0.0, -1.0] and recs["front_face"][0] == 0   # e1 x e2 = +z faces away: flipped
+    assert recs["normal"][1].tolist() == [0.0, 0.0, 1.0] and recs["front_face"][1] == 1
+    assert recs["normal"][3].tolist() == [0.0, 0.0, 1.0]
+    # coincident triangles: the lower index wins, whichever order the arrays list them in
+    a = np.array([[-5, -5, 0], [5, -5, 0], [0, 5, 0]], np.float32)
+    flipped = a[[0, 2, 1]]
+    for first, second, want_ff in [(a, flipped, 0), (flipped, a, 1)]:
+        m = (np.concatenate([first, second]), np.array([[0, 1, 2], [3, 4, 5]], np.uint32))
+        o1 = np.array([mesh_object(0, (0, 0, 5), abi.RT_MAT_MIRROR)], dtype=abi.OBJECT_DTYPE)
+        _, _, r, _ = ob.OracleScene(o1, meshes=[m]).simulate(rays[:1], 20.0, 1, seed=0)
+        assert r["t"][0] == 5.0 and r["front_face"][0] == want_ff

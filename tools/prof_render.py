@@ -13,12 +13,14 @@ spp = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 cfgname = sys.argv[5] if len(sys.argv) > 5 else "c2"
 engine.init(0)
-cfg = synth.config_c2(w, h) if cfgname == "c2" else synth.config_c4(w, h)
-sc = engine.Scene(cfg["objects"])
+cfg = {"c2": synth.config_c2, "c3": synth.config_c3, "c4": synth.config_c4}[cfgname](w, h)
+t0 = __import__("time").perf_counter()
+sc = engine.Scene(cfg["objects"], meshes=cfg.get("meshes"))
+print(f"scene build {(__import__('time').perf_counter() - t0)*1e3:.1f} ms", flush=True)
 st = SimulationSettingsConfig(cfg["infinity_distance"], cfg["max_bounces"])
 import time
 for r in range(reps):
     t0 = time.perf_counter()
     fb, fid, ft, seg, tot = sc.render(cfg["gen"], spp, st, seed=cfg["seed"])
     dt = time.perf_counter() - t0
-    print(f"rep {r}: {tot} segments, host wall {dt*1e3:.1f} ms (includes alloc+copies)", flush=True)
+    print(f"rep {r}: {tot} segments, mesh-hit pixels {(fid == 0).mean():.2f}, host wall {dt*1e3:.1f} ms (includes alloc+copies)", flush=True)
