@@ -254,11 +254,17 @@ __device__ __noinline__ bool mesh_first_hit(const DevScene& sc, uint32_t root, F
         tn = tn - 1e-6f * __builtin_fabsf(tn) - 1e-7f;
         tf = tf + 1e-6f * __builtin_fabsf(tf) + 1e-7f;
         if (!(tn <= tf) || tf < 0.0f || tn > best) continue;
-        const uint32_t cnt = __float_as_uint(n.hi.w), first = __float_as_uint(n.lo.w);
+        const uint32_t meta = __float_as_uint(n.hi.w), first = __float_as_uint(n.lo.w);
+        const uint32_t cnt = meta & 0x0fffffffu;
         if (cnt == 0) {
+            // near child first (the left child holds the lower centroids along the split axis): its hits shrink `best`
+            // before the far child is popped.  Order never changes the result, only how much is culled.
+            const uint32_t axis = meta >> 30;
+            const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+            const uint32_t far_first = da >= 0.0f ? 1u : 0u;
             if (sp + 2 <= kBvhStack) {
-                stack[sp++] = first;
-                stack[sp++] = first + 1;
+                stack[sp++] = first + far_first;
+                stack[sp++] = first + (far_first ^ 1u);
             }
             continue;
         }

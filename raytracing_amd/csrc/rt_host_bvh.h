@@ -109,7 +109,7 @@ struct BvhBuild {
         nodes.push_back(BvhNode{});
         nodes.push_back(BvhNode{});
         n.lo.w = bits(left);
-        n.hi.w = bits(0u);
+        n.hi.w = bits((uint32_t)axis << 30);  // count 0 = interior; split axis in the top bits (left = lower centroids)
         nodes[self] = n;
         build(left, b, mid, depth + 1);
         build(left + 1, mid, e, depth + 1);
