@@ -24,6 +24,7 @@ struct SimulationConfig {
     std::vector<RtObject> objects;    // Scene.objects order (scene_config.rs:25-52)
     std::vector<RtShapeNode> nodes;   // Union / Intersection / Difference trees
     std::vector<RtRay> rays;          // Scene.rays order (scene_config.rs:55-110)
+    std::vector<RtRayGenerator> generators;  // [[scene.ray_generators]] as given, for the render loop (rt_hip_render)
 };
 
 inline const Value& req(const Value& t, const std::string& key, const std::string& where)
@@ -236,6 +237,18 @@ inline SimulationConfig from_toml(const std::string& text)
                 us[c] = u[c] / (float)cu;
                 vs[c] = v[c] / (float)cv;
             }
+            RtRayGenerator g{};  // raw direction: the device normalises it once, like scene_config.rs:67
+            g.kind = RT_GEN_PARALLEL_GRID;
+            g.count_u = cu;
+            g.count_v = cv;
+            g.current_ior = ior;
+            for (int c = 0; c < 3; ++c) {
+                g.a[c] = a[c];
+                g.u[c] = u[c];
+                g.v[c] = v[c];
+                g.direction[c] = dir[c];
+            }
+            cfg.generators.push_back(g);
             normalize3(dir);
             for (uint32_t i = 0; i < cu; ++i)
                 for (uint32_t j = 0; j < cv; ++j) {
@@ -257,6 +270,18 @@ inline SimulationConfig from_toml(const std::string& text)
                 us[c] = u[c] / (float)cu;
                 vs[c] = v[c] / (float)cv;
             }
+            RtRayGenerator g{};
+            g.kind = RT_GEN_PROJECTOR;
+            g.count_u = cu;
+            g.count_v = cv;
+            g.current_ior = ior;
+            for (int c = 0; c < 3; ++c) {
+                g.a[c] = a[c];
+                g.corner[c] = corner[c];
+                g.u[c] = u[c];
+                g.v[c] = v[c];
+            }
+            cfg.generators.push_back(g);
             for (uint32_t i = 0; i < cu; ++i)
                 for (uint32_t j = 0; j < cv; ++j) {
                     RtRay r{};
