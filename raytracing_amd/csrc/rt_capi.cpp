@@ -287,17 +287,9 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
                 uint32_t mi;
                 std::memcpy(&mi, &o.shape_param[0], 4);
                 if (mi >= desc->n_meshes) return fail(RT_ERR_INVALID, "object " + std::to_string(k) + ": mesh index out of range");
-                if (mesh_roots[mi] == rt::kNoMesh && desc->meshes[mi].n_triangles)
-                    mesh_roots[mi] = rt::host::build_mesh_bvh(desc->meshes[mi], bvh_nodes, tris);
+                if (mesh_roots[mi] == rt::kNoMesh) mesh_roots[mi] = rt::host::build_mesh_bvh(desc->meshes[mi], bvh_nodes, tris);
                 mesh_root = mesh_roots[mi];
-                if (mesh_root == rt::kNoMesh) {  // empty mesh: NaN bounds fail every slab test (an inverted box would not:
-                    rt::BvhNode e{};             // min / max of the two plane distances re-orders it into all of space)
-                    const float nan = std::numeric_limits<float>::quiet_NaN();
-                    e.lo = make_float4(nan, nan, nan, 0.f);
-                    e.hi = make_float4(nan, nan, nan, 0.f);
-                    mesh_root = mesh_roots[mi] = (uint32_t)bvh_nodes.size();
-                    bvh_nodes.push_back(e);
-                }
+                if (tris.size() >= (1ull << 28)) return fail(RT_ERR_INVALID, "more than 2^28 triangles in one scene");
             } else if (rt::host::emit_shape(o.shape, o.shape_param, shape_nodes, n_shape_nodes, pr, 0, 0, err) < 0)
                 return fail(RT_ERR_INVALID, "object " + std::to_string(k) + ": " + err);
             if (pr.max_hits > rt::kCxMaxHits || pr.max_stack > rt::kCxStack)

@@ -230,6 +230,23 @@ __device__ __forceinline__ bool tri_box_holds(float a, float e1, float e2, float
 // exact: node boxes are unions of those triangle boxes (padded once more) and the slab test is widened past its own
 // rounding, so a node is skipped only when none of its triangles can pass; the result equals the oracle's brute-force
 // loop bit for bit.
+// Widened slab test of one child box (see mesh_first_hit): entry distance, or NaN-free "miss" = +inf.
+__device__ __forceinline__ float bvh_child_entry(float4 lo, float4 hi, F3 o, F3 inv, F3 ro, float best)
+{
+    // fmin / fmax drop the NaN of 0 * inf (origin on a slab plane, zero direction component); NaN bounds (absent child)
+    // leave tn = tf = NaN, which the final comparison rejects
+    float t0 = ((lo.x - ro.x) - o.x) * inv.x, t1 = ((hi.x + ro.x) - o.x) * inv.x;
+    float tn = __builtin_fminf(t0, t1), tf = __builtin_fmaxf(t0, t1);
+    t0 = ((lo.y - ro.y) - o.y) * inv.y; t1 = ((hi.y + ro.y) - o.y) * inv.y;
+    tn = __builtin_fmaxf(tn, __builtin_fminf(t0, t1)); tf = __builtin_fminf(tf, __builtin_fmaxf(t0, t1));
+    t0 = ((lo.z - ro.z) - o.z) * inv.z; t1 = ((hi.z + ro.z) - o.z) * inv.z;
+    tn = __builtin_fmaxf(tn, __builtin_fminf(t0, t1)); tf = __builtin_fminf(tf, __builtin_fmaxf(t0, t1));
+    tn = tn - 1e-6f * __builtin_fabsf(tn) - 1e-7f;
+    tf = tf + 1e-6f * __builtin_fabsf(tf) + 1e-7f;
+    const bool hit = tn <= tf && tf >= 0.0f && tn <= best;
+    return hit ? tn : __builtin_inff();
+}
+
 __device__ __noinline__ bool mesh_first_hit(const DevScene& sc, uint32_t root, F3 o, F3 d, CxHit& out)
 {
     const float inf = __builtin_inff();
@@ -239,59 +256,64 @@ __device__ __noinline__ bool mesh_first_hit(const DevScene& sc, uint32_t root, F
     // o + t d is rounded relative to |o| as well as to the box: grow every box by 8 ulp of the origin
     const F3 ro = f3(4.8e-7f * __builtin_fabsf(o.x), 4.8e-7f * __builtin_fabsf(o.y), 4.8e-7f * __builtin_fabsf(o.z));
     uint32_t stack[kBvhStack];
+    float stack_t[kBvhStack];
     int sp = 0;
-    stack[sp++] = root;
-    while (sp > 0) {
-        const uint32_t ni = stack[--sp];
-        const BvhNode n = sc.bvh_nodes[ni];
-        // slab test; fmin / fmax drop the NaN of 0 * inf (origin on a slab plane, zero direction component)
-        float t0 = ((n.lo.x - ro.x) - o.x) * inv.x, t1 = ((n.hi.x + ro.x) - o.x) * inv.x;
-        float tn = __builtin_fminf(t0, t1), tf = __builtin_fmaxf(t0, t1);
-        t0 = ((n.lo.y - ro.y) - o.y) * inv.y; t1 = ((n.hi.y + ro.y) - o.y) * inv.y;
-        tn = __builtin_fmaxf(tn, __builtin_fminf(t0, t1)); tf = __builtin_fminf(tf, __builtin_fmaxf(t0, t1));
-        t0 = ((n.lo.z - ro.z) - o.z) * inv.z; t1 = ((n.hi.z + ro.z) - o.z) * inv.z;
-        tn = __builtin_fmaxf(tn, __builtin_fminf(t0, t1)); tf = __builtin_fminf(tf, __builtin_fmaxf(t0, t1));
-        tn = tn - 1e-6f * __builtin_fabsf(tn) - 1e-7f;
-        tf = tf + 1e-6f * __builtin_fabsf(tf) + 1e-7f;
-        if (!(tn <= tf) || tf < 0.0f || tn > best) continue;
-        const uint32_t meta = __float_as_uint(n.hi.w), first = __float_as_uint(n.lo.w);
-        const uint32_t cnt = meta & 0x0fffffffu;
-        if (cnt == 0) {
-            // near child first (the left child holds the lower centroids along the split axis): its hits shrink `best`
-            // before the far child is popped.  Order never changes the result, only how much is culled.
-            const uint32_t axis = meta >> 30;
-            const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
-            const uint32_t far_first = da >= 0.0f ? 1u : 0u;
-            if (sp + 2 <= kBvhStack) {
-                stack[sp++] = first + far_first;
-                stack[sp++] = first + (far_first ^ 1u);
+    uint32_t cur = root;
+    for (;;) {
+        if (cur & kBvhLeaf) {
+            const uint32_t first = (cur & 0x7fffffffu) >> 3, cnt = cur & 7u;
+            for (uint32_t k = first; k < first + cnt; ++k) {
+                const TriDev tr = sc.tris[k];
+                const F3 v0 = f3(tr.v0.x, tr.v0.y, tr.v0.z), e1 = f3(tr.e1.x, tr.e1.y, tr.e1.z), e2 = f3(tr.e2.x, tr.e2.y, tr.e2.z);
+                const F3 pvec = cross(d, e2);
+                const float det = dot(e1, pvec);
+                if (__builtin_fabsf(det) < 1e-12f) continue;
+                const float idet = 1.0f / det;
+                const F3 tvec = o - v0;
+                const float u = dot(tvec, pvec) * idet;
+                if (u < 0.0f || u > 1.0f) continue;
+                const F3 qvec = cross(tvec, e1);
+                const float v = dot(d, qvec) * idet;
+                if (v < 0.0f || u + v > 1.0f) continue;
+                const float t = dot(e2, qvec) * idet;
+                if (!(t > kTMin && t < inf)) continue;
+                const F3 p = o + t * d;
+                if (!(tri_box_holds(v0.x, e1.x, e2.x, p.x) && tri_box_holds(v0.y, e1.y, e2.y, p.y) && tri_box_holds(v0.z, e1.z, e2.z, p.z))) continue;
+                const uint32_t id = __float_as_uint(tr.v0.w);
+                if (t < best || (t == best && id < best_id)) {
+                    best = t;
+                    best_id = id;
+                    best_k = k;
+                }
             }
-            continue;
-        }
-        for (uint32_t k = first; k < first + cnt; ++k) {
-            const TriDev tr = sc.tris[k];
-            const F3 v0 = f3(tr.v0.x, tr.v0.y, tr.v0.z), e1 = f3(tr.e1.x, tr.e1.y, tr.e1.z), e2 = f3(tr.e2.x, tr.e2.y, tr.e2.z);
-            const F3 pvec = cross(d, e2);
-            const float det = dot(e1, pvec);
-            if (__builtin_fabsf(det) < 1e-12f) continue;
-            const float idet = 1.0f / det;
-            const F3 tvec = o - v0;
-            const float u = dot(tvec, pvec) * idet;
-            if (u < 0.0f || u > 1.0f) continue;
-            const F3 qvec = cross(tvec, e1);
-            const float v = dot(d, qvec) * idet;
-            if (v < 0.0f || u + v > 1.0f) continue;
-            const float t = dot(e2, qvec) * idet;
-            if (!(t > kTMin && t < inf)) continue;
-            const F3 p = o + t * d;
-            if (!(tri_box_holds(v0.x, e1.x, e2.x, p.x) && tri_box_holds(v0.y, e1.y, e2.y, p.y) && tri_box_holds(v0.z, e1.z, e2.z, p.z))) continue;
-            const uint32_t id = __float_as_uint(tr.v0.w);
-            if (t < best || (t == best && id < best_id)) {
-                best = t;
-                best_id = id;
-                best_k = k;
+        } else {
+            const BvhNode n = sc.bvh_nodes[cur];
+            const float tn0 = bvh_child_entry(n.lo0, n.hi0, o, inv, ro, best);
+            const float tn1 = bvh_child_entry(n.lo1, n.hi1, o, inv, ro, best);
+            const uint32_t c0 = __float_as_uint(n.lo0.w), c1 = __float_as_uint(n.lo1.w);
+            if (tn0 < inf || tn1 < inf) {
+                // nearer child now, the other one (if hit) later; visiting order never changes the result
+                const bool first0 = tn0 <= tn1;
+                if (tn0 < inf && tn1 < inf && sp < kBvhStack) {
+                    stack[sp] = first0 ? c1 : c0;
+                    stack_t[sp] = first0 ? tn1 : tn0;
+                    ++sp;
+                }
+                cur = first0 ? c0 : c1;
+                continue;
             }
         }
+        // pop, skipping entries the best hit found since has put out of reach
+        bool got = false;
+        while (sp > 0) {
+            --sp;
+            if (stack_t[sp] <= best) {
+                cur = stack[sp];
+                got = true;
+                break;
+            }
+        }
+        if (!got) break;
     }
     if (best_id == 0xffffffffu) return false;
     const TriDev tr = sc.tris[best_k];

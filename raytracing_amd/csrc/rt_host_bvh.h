@@ -1,10 +1,11 @@
 // rt_host_bvh.h — host-side BVH build for triangle meshes (extension).  Median split on the longest
-// centroid axis, leaves of <= 4 triangles.  A hit must lie inside its triangle's padded box (part of the mesh
+// centroid axis, leaves of <= 4 triangles, each node carrying the boxes of its two children.  A hit must lie inside its triangle's padded box (part of the mesh
 // semantics), node boxes contain those boxes, so the traversal never excludes a triangle the exact test would accept.
 #pragma once
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <numeric>
 #include <vector>
 
@@ -66,18 +67,13 @@ struct BvhBuild {
         }
     }
 
-    // builds the subtree of order[b, e) into nodes[self]
-    void build(uint32_t self, size_t b, size_t e, int depth)
+    // Builds the subtree of order[b, e); returns its child reference and its padded box.
+    uint32_t build(size_t b, size_t e, int depth, float lo[3], float hi[3])
     {
         max_depth = std::max(max_depth, depth);
-        float lo[3], hi[3];
         bounds(b, e, lo, hi);
-        BvhNode n{};
-        n.lo = make_float4(lo[0], lo[1], lo[2], 0.f);
-        n.hi = make_float4(hi[0], hi[1], hi[2], 0.f);
-        if (e - b <= 4 || depth >= kBvhStack - 4) {
-            n.lo.w = bits((uint32_t)tris.size());
-            n.hi.w = bits((uint32_t)(e - b));
+        if (e - b <= (size_t)kBvhLeafTris) {
+            const uint32_t first = (uint32_t)tris.size();
             for (size_t k = b; k < e; ++k) {
                 const uint32_t t = order[k];
                 const float *a = vert(t, 0), *p1 = vert(t, 1), *p2 = vert(t, 2);
@@ -87,10 +83,9 @@ struct BvhBuild {
                 td.e2 = make_float4(p2[0] - a[0], p2[1] - a[1], p2[2] - a[2], 0.f);
                 tris.push_back(td);
             }
-            nodes[self] = n;
-            return;
+            return kBvhLeaf | (first << 3) | (uint32_t)(e - b);
         }
-        // longest centroid axis, median split
+        // longest centroid axis, median split (halves the range, so depth <= 28 for the 2^28 triangles allowed)
         float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (size_t k = b; k < e; ++k) {
             const float c[3] = {cx[order[k]], cy[order[k]], cz[order[k]]};
@@ -105,16 +100,29 @@ struct BvhBuild {
         const std::vector<float>& key = axis == 0 ? cx : (axis == 1 ? cy : cz);
         const size_t mid = b + (e - b) / 2;
         std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
-        const uint32_t left = (uint32_t)nodes.size();
+        const uint32_t self = (uint32_t)nodes.size();
         nodes.push_back(BvhNode{});
-        nodes.push_back(BvhNode{});
-        n.lo.w = bits(left);
-        n.hi.w = bits((uint32_t)axis << 30);  // count 0 = interior; split axis in the top bits (left = lower centroids)
+        float l0[3], h0[3], l1[3], h1[3];
+        const uint32_t c0 = build(b, mid, depth + 1, l0, h0);
+        const uint32_t c1 = build(mid, e, depth + 1, l1, h1);
+        BvhNode n{};
+        n.lo0 = make_float4(l0[0], l0[1], l0[2], bits(c0));
+        n.hi0 = make_float4(h0[0], h0[1], h0[2], 0.f);
+        n.lo1 = make_float4(l1[0], l1[1], l1[2], bits(c1));
+        n.hi1 = make_float4(h1[0], h1[1], h1[2], 0.f);
         nodes[self] = n;
-        build(left, b, mid, depth + 1);
-        build(left + 1, mid, e, depth + 1);
+        return self;
     }
 };
+
+// A node whose two children cannot be hit (NaN bounds): the root of an empty mesh, and the filler of a one-leaf root.
+inline BvhNode dead_node()
+{
+    const float nan = std::numeric_limits<float>::quiet_NaN();
+    BvhNode n{};
+    n.lo0 = n.hi0 = n.lo1 = n.hi1 = make_float4(nan, nan, nan, 0.f);
+    return n;
+}
 
 // Appends the BVH of mesh `m` to the global arrays; returns the root node index.
 inline uint32_t build_mesh_bvh(const RtMesh& m, std::vector<BvhNode>& nodes, std::vector<TriDev>& tris)
@@ -132,10 +140,20 @@ inline uint32_t build_mesh_bvh(const RtMesh& m, std::vector<BvhNode>& nodes, std
         bb.cy[t] = (a[1] + b[1] + c[1]) * (1.0f / 3.0f);
         bb.cz[t] = (a[2] + b[2] + c[2]) * (1.0f / 3.0f);
     }
-    const uint32_t root = (uint32_t)nodes.size();
-    nodes.push_back(BvhNode{});
-    bb.build(root, 0, n, 0);
-    return root;
+    if (n == 0) {
+        nodes.push_back(dead_node());
+        return (uint32_t)nodes.size() - 1;
+    }
+    float lo[3], hi[3];
+    const size_t before = nodes.size();
+    const uint32_t ref = bb.build(0, n, 0, lo, hi);
+    if (!(ref & kBvhLeaf)) return ref;  // the first node pushed, == before
+    (void)before;
+    BvhNode root = dead_node();  // <= 4 triangles: a root whose only child is that leaf
+    root.lo0 = make_float4(lo[0], lo[1], lo[2], BvhBuild::bits(ref));
+    root.hi0 = make_float4(hi[0], hi[1], hi[2], 0.f);
+    nodes.push_back(root);
+    return (uint32_t)nodes.size() - 1;
 }
 
 }  // namespace host
