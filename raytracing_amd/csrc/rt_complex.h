@@ -230,21 +230,30 @@ __device__ __forceinline__ bool tri_box_holds(float a, float e1, float e2, float
 // exact: node boxes are unions of those triangle boxes (padded once more) and the slab test is widened past its own
 // rounding, so a node is skipped only when none of its triangles can pass; the result equals the oracle's brute-force
 // loop bit for bit.
-// Widened slab test of one child box (see mesh_first_hit): entry distance, or NaN-free "miss" = +inf.
-__device__ __forceinline__ float bvh_child_entry(float4 lo, float4 hi, F3 o, F3 inv, F3 ro, float best)
+// Widened slab test of one child box (see mesh_first_hit): entry distance, or +inf for a miss.  o_lo / o_hi are the
+// origin moved 8 ulp up / down, which grows the box by what the rounding of o + t d can add on top of the box's own pad.
+__device__ __forceinline__ float bvh_child_entry(float4 lo, float4 hi, F3 o_lo, F3 o_hi, F3 inv, float best)
 {
     // fmin / fmax drop the NaN of 0 * inf (origin on a slab plane, zero direction component); NaN bounds (absent child)
     // leave tn = tf = NaN, which the final comparison rejects
-    float t0 = ((lo.x - ro.x) - o.x) * inv.x, t1 = ((hi.x + ro.x) - o.x) * inv.x;
+    float t0 = (lo.x - o_lo.x) * inv.x, t1 = (hi.x - o_hi.x) * inv.x;
     float tn = __builtin_fminf(t0, t1), tf = __builtin_fmaxf(t0, t1);
-    t0 = ((lo.y - ro.y) - o.y) * inv.y; t1 = ((hi.y + ro.y) - o.y) * inv.y;
+    t0 = (lo.y - o_lo.y) * inv.y; t1 = (hi.y - o_hi.y) * inv.y;
     tn = __builtin_fmaxf(tn, __builtin_fminf(t0, t1)); tf = __builtin_fminf(tf, __builtin_fmaxf(t0, t1));
-    t0 = ((lo.z - ro.z) - o.z) * inv.z; t1 = ((hi.z + ro.z) - o.z) * inv.z;
+    t0 = (lo.z - o_lo.z) * inv.z; t1 = (hi.z - o_hi.z) * inv.z;
     tn = __builtin_fmaxf(tn, __builtin_fminf(t0, t1)); tf = __builtin_fminf(tf, __builtin_fmaxf(t0, t1));
-    tn = tn - 1e-6f * __builtin_fabsf(tn) - 1e-7f;
-    tf = tf + 1e-6f * __builtin_fabsf(tf) + 1e-7f;
+    tn = __builtin_fmaf(__builtin_fabsf(tn), -1e-6f, tn) - 1e-7f;  // a cull margin, not a reported value: fused is fine
+    tf = __builtin_fmaf(__builtin_fabsf(tf), 1e-6f, tf) + 1e-7f;
     const bool hit = tn <= tf && tf >= 0.0f && tn <= best;
     return hit ? tn : __builtin_inff();
+}
+
+__device__ __forceinline__ void bvh_order(float& ta, uint32_t& ca, float& tb, uint32_t& cb)
+{
+    const bool swap = tb < ta;
+    const float tl = swap ? tb : ta, th = swap ? ta : tb;
+    const uint32_t cl = swap ? cb : ca, ch = swap ? ca : cb;
+    ta = tl; tb = th; ca = cl; cb = ch;
 }
 
 __device__ __noinline__ bool mesh_first_hit(const DevScene& sc, uint32_t root, F3 o, F3 d, CxHit& out)
@@ -253,67 +262,78 @@ __device__ __noinline__ bool mesh_first_hit(const DevScene& sc, uint32_t root, F
     float best = inf;
     uint32_t best_id = 0xffffffffu, best_k = 0;
     const F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    // o + t d is rounded relative to |o| as well as to the box: grow every box by 8 ulp of the origin
     const F3 ro = f3(4.8e-7f * __builtin_fabsf(o.x), 4.8e-7f * __builtin_fabsf(o.y), 4.8e-7f * __builtin_fabsf(o.z));
+    const F3 o_lo = o + ro, o_hi = o - ro;
     uint32_t stack[kBvhStack];
     float stack_t[kBvhStack];
     int sp = 0;
+    constexpr uint32_t kDone = 0x7fffffffu;  // not a node index (node counts stay far below 2^31)
     uint32_t cur = root;
-    for (;;) {
-        if (cur & kBvhLeaf) {
-            const uint32_t first = (cur & 0x7fffffffu) >> 3, cnt = cur & 7u;
-            for (uint32_t k = first; k < first + cnt; ++k) {
-                const TriDev tr = sc.tris[k];
-                const F3 v0 = f3(tr.v0.x, tr.v0.y, tr.v0.z), e1 = f3(tr.e1.x, tr.e1.y, tr.e1.z), e2 = f3(tr.e2.x, tr.e2.y, tr.e2.z);
-                const F3 pvec = cross(d, e2);
-                const float det = dot(e1, pvec);
-                if (__builtin_fabsf(det) < 1e-12f) continue;
-                const float idet = 1.0f / det;
-                const F3 tvec = o - v0;
-                const float u = dot(tvec, pvec) * idet;
-                if (u < 0.0f || u > 1.0f) continue;
-                const F3 qvec = cross(tvec, e1);
-                const float v = dot(d, qvec) * idet;
-                if (v < 0.0f || u + v > 1.0f) continue;
-                const float t = dot(e2, qvec) * idet;
-                if (!(t > kTMin && t < inf)) continue;
-                const F3 p = o + t * d;
-                if (!(tri_box_holds(v0.x, e1.x, e2.x, p.x) && tri_box_holds(v0.y, e1.y, e2.y, p.y) && tri_box_holds(v0.z, e1.z, e2.z, p.z))) continue;
-                const uint32_t id = __float_as_uint(tr.v0.w);
-                if (t < best || (t == best && id < best_id)) {
-                    best = t;
-                    best_id = id;
-                    best_k = k;
-                }
-            }
-        } else {
+    // "while-while": every lane first descends to its next leaf, then the wave tests leaves together, so the expensive
+    // triangle code runs with as many lanes as possible
+    while (cur != kDone) {
+        while (!(cur & kBvhLeaf) && cur != kDone) {
             const BvhNode n = sc.bvh_nodes[cur];
-            const float tn0 = bvh_child_entry(n.lo0, n.hi0, o, inv, ro, best);
-            const float tn1 = bvh_child_entry(n.lo1, n.hi1, o, inv, ro, best);
-            const uint32_t c0 = __float_as_uint(n.lo0.w), c1 = __float_as_uint(n.lo1.w);
-            if (tn0 < inf || tn1 < inf) {
-                // nearer child now, the other one (if hit) later; visiting order never changes the result
-                const bool first0 = tn0 <= tn1;
-                if (tn0 < inf && tn1 < inf && sp < kBvhStack) {
-                    stack[sp] = first0 ? c1 : c0;
-                    stack_t[sp] = first0 ? tn1 : tn0;
-                    ++sp;
+            float t0 = bvh_child_entry(n.lo[0], n.hi[0], o_lo, o_hi, inv, best), t1 = bvh_child_entry(n.lo[1], n.hi[1], o_lo, o_hi, inv, best);
+            float t2 = bvh_child_entry(n.lo[2], n.hi[2], o_lo, o_hi, inv, best), t3 = bvh_child_entry(n.lo[3], n.hi[3], o_lo, o_hi, inv, best);
+            uint32_t c0 = __float_as_uint(n.lo[0].w), c1 = __float_as_uint(n.lo[1].w), c2 = __float_as_uint(n.lo[2].w), c3 = __float_as_uint(n.lo[3].w);
+            // sort the four (entry, child) pairs by entry distance (misses = +inf go last); order never changes the
+            // result, it only lets the nearest hit cull the rest
+            bvh_order(t0, c0, t1, c1);
+            bvh_order(t2, c2, t3, c3);
+            bvh_order(t0, c0, t2, c2);
+            bvh_order(t1, c1, t3, c3);
+            bvh_order(t1, c1, t2, c2);
+            if (t3 < inf && sp < kBvhStack) { stack[sp] = c3; stack_t[sp] = t3; ++sp; }
+            if (t2 < inf && sp < kBvhStack) { stack[sp] = c2; stack_t[sp] = t2; ++sp; }
+            if (t1 < inf && sp < kBvhStack) { stack[sp] = c1; stack_t[sp] = t1; ++sp; }
+            if (t0 < inf) {
+                cur = c0;
+            } else {
+                cur = kDone;  // pop, skipping entries the best hit found since has put out of reach
+                while (sp > 0) {
+                    --sp;
+                    if (stack_t[sp] <= best) {
+                        cur = stack[sp];
+                        break;
+                    }
                 }
-                cur = first0 ? c0 : c1;
-                continue;
             }
         }
-        // pop, skipping entries the best hit found since has put out of reach
-        bool got = false;
+        if (cur == kDone) break;
+        const uint32_t first = (cur & 0x7fffffffu) >> 3, cnt = cur & 7u;
+        for (uint32_t k = first; k < first + cnt; ++k) {
+            const TriDev tr = sc.tris[k];
+            const F3 v0 = f3(tr.v0.x, tr.v0.y, tr.v0.z), e1 = f3(tr.e1.x, tr.e1.y, tr.e1.z), e2 = f3(tr.e2.x, tr.e2.y, tr.e2.z);
+            const F3 pvec = cross(d, e2);
+            const float det = dot(e1, pvec);
+            if (__builtin_fabsf(det) < 1e-12f) continue;
+            const float idet = 1.0f / det;
+            const F3 tvec = o - v0;
+            const float u = dot(tvec, pvec) * idet;
+            if (u < 0.0f || u > 1.0f) continue;
+            const F3 qvec = cross(tvec, e1);
+            const float v = dot(d, qvec) * idet;
+            if (v < 0.0f || u + v > 1.0f) continue;
+            const float t = dot(e2, qvec) * idet;
+            if (!(t > kTMin && t < inf)) continue;
+            const F3 p = o + t * d;
+            if (!(tri_box_holds(v0.x, e1.x, e2.x, p.x) && tri_box_holds(v0.y, e1.y, e2.y, p.y) && tri_box_holds(v0.z, e1.z, e2.z, p.z))) continue;
+            const uint32_t id = __float_as_uint(tr.v0.w);
+            if (t < best || (t == best && id < best_id)) {
+                best = t;
+                best_id = id;
+                best_k = k;
+            }
+        }
+        cur = kDone;
         while (sp > 0) {
             --sp;
             if (stack_t[sp] <= best) {
                 cur = stack[sp];
-                got = true;
                 break;
             }
         }
-        if (!got) break;
     }
     if (best_id == 0xffffffffu) return false;
     const TriDev tr = sc.tris[best_k];

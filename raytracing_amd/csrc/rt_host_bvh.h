@@ -1,5 +1,5 @@
 // rt_host_bvh.h — host-side BVH build for triangle meshes (extension).  Median split on the longest
-// centroid axis, leaves of <= 4 triangles, each node carrying the boxes of its two children.  A hit must lie inside its triangle's padded box (part of the mesh
+// centroid axis twice per node (4-wide nodes), leaves of <= 4 triangles, each node carrying the boxes of its children.  A hit must lie inside its triangle's padded box (part of the mesh
 // semantics), node boxes contain those boxes, so the traversal never excludes a triangle the exact test would accept.
 #pragma once
 #include <algorithm>
@@ -67,25 +67,24 @@ struct BvhBuild {
         }
     }
 
-    // Builds the subtree of order[b, e); returns its child reference and its padded box.
-    uint32_t build(size_t b, size_t e, int depth, float lo[3], float hi[3])
+    uint32_t make_leaf(size_t b, size_t e)
     {
-        max_depth = std::max(max_depth, depth);
-        bounds(b, e, lo, hi);
-        if (e - b <= (size_t)kBvhLeafTris) {
-            const uint32_t first = (uint32_t)tris.size();
-            for (size_t k = b; k < e; ++k) {
-                const uint32_t t = order[k];
-                const float *a = vert(t, 0), *p1 = vert(t, 1), *p2 = vert(t, 2);
-                TriDev td{};
-                td.v0 = make_float4(a[0], a[1], a[2], bits(t));
-                td.e1 = make_float4(p1[0] - a[0], p1[1] - a[1], p1[2] - a[2], 0.f);
-                td.e2 = make_float4(p2[0] - a[0], p2[1] - a[1], p2[2] - a[2], 0.f);
-                tris.push_back(td);
-            }
-            return kBvhLeaf | (first << 3) | (uint32_t)(e - b);
+        const uint32_t first = (uint32_t)tris.size();
+        for (size_t k = b; k < e; ++k) {
+            const uint32_t t = order[k];
+            const float *a = vert(t, 0), *p1 = vert(t, 1), *p2 = vert(t, 2);
+            TriDev td{};
+            td.v0 = make_float4(a[0], a[1], a[2], bits(t));
+            td.e1 = make_float4(p1[0] - a[0], p1[1] - a[1], p1[2] - a[2], 0.f);
+            td.e2 = make_float4(p2[0] - a[0], p2[1] - a[1], p2[2] - a[2], 0.f);
+            tris.push_back(td);
         }
-        // longest centroid axis, median split (halves the range, so depth <= 28 for the 2^28 triangles allowed)
+        return kBvhLeaf | (first << 3) | (uint32_t)(e - b);
+    }
+
+    // Median split of order[b, e) on its longest centroid axis; returns the split position.
+    size_t split(size_t b, size_t e)
+    {
         float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (size_t k = b; k < e; ++k) {
             const float c[3] = {cx[order[k]], cy[order[k]], cz[order[k]]};
@@ -100,29 +99,45 @@ struct BvhBuild {
         const std::vector<float>& key = axis == 0 ? cx : (axis == 1 ? cy : cz);
         const size_t mid = b + (e - b) / 2;
         std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
+        return mid;
+    }
+
+    // Builds the node of order[b, e) (more than one leaf's worth): two levels of median splits give up to four parts;
+    // a part that fits a leaf becomes one, the others recurse.  Each level quarters the range: depth <= 14 for 2^28.
+    uint32_t build(size_t b, size_t e, int depth)
+    {
+        max_depth = std::max(max_depth, depth);
         const uint32_t self = (uint32_t)nodes.size();
         nodes.push_back(BvhNode{});
-        float l0[3], h0[3], l1[3], h1[3];
-        const uint32_t c0 = build(b, mid, depth + 1, l0, h0);
-        const uint32_t c1 = build(mid, e, depth + 1, l1, h1);
-        BvhNode n{};
-        n.lo0 = make_float4(l0[0], l0[1], l0[2], bits(c0));
-        n.hi0 = make_float4(h0[0], h0[1], h0[2], 0.f);
-        n.lo1 = make_float4(l1[0], l1[1], l1[2], bits(c1));
-        n.hi1 = make_float4(h1[0], h1[1], h1[2], 0.f);
+        size_t cut[5];
+        int parts = 0;
+        const size_t mid = split(b, e);
+        cut[parts++] = b;
+        if (mid - b > (size_t)kBvhLeafTris) cut[parts++] = split(b, mid);
+        cut[parts++] = mid;
+        if (e - mid > (size_t)kBvhLeafTris) cut[parts++] = split(mid, e);
+        cut[parts] = e;
+        BvhNode n = dead_node();
+        for (int i = 0; i < parts; ++i) {
+            float lo[3], hi[3];
+            bounds(cut[i], cut[i + 1], lo, hi);
+            const uint32_t ref = cut[i + 1] - cut[i] <= (size_t)kBvhLeafTris ? make_leaf(cut[i], cut[i + 1]) : build(cut[i], cut[i + 1], depth + 1);
+            n.lo[i] = make_float4(lo[0], lo[1], lo[2], bits(ref));
+            n.hi[i] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        }
         nodes[self] = n;
         return self;
     }
-};
 
-// A node whose two children cannot be hit (NaN bounds): the root of an empty mesh, and the filler of a one-leaf root.
-inline BvhNode dead_node()
-{
-    const float nan = std::numeric_limits<float>::quiet_NaN();
-    BvhNode n{};
-    n.lo0 = n.hi0 = n.lo1 = n.hi1 = make_float4(nan, nan, nan, 0.f);
-    return n;
-}
+    // A node none of whose children can be hit (NaN bounds): the root of an empty mesh, and the blank every node starts from.
+    static BvhNode dead_node()
+    {
+        const float nan = std::numeric_limits<float>::quiet_NaN();
+        BvhNode n{};
+        for (int i = 0; i < 4; ++i) n.lo[i] = n.hi[i] = make_float4(nan, nan, nan, 0.f);
+        return n;
+    }
+};
 
 // Appends the BVH of mesh `m` to the global arrays; returns the root node index.
 inline uint32_t build_mesh_bvh(const RtMesh& m, std::vector<BvhNode>& nodes, std::vector<TriDev>& tris)
@@ -140,18 +155,14 @@ inline uint32_t build_mesh_bvh(const RtMesh& m, std::vector<BvhNode>& nodes, std
         bb.cy[t] = (a[1] + b[1] + c[1]) * (1.0f / 3.0f);
         bb.cz[t] = (a[2] + b[2] + c[2]) * (1.0f / 3.0f);
     }
-    if (n == 0) {
-        nodes.push_back(dead_node());
-        return (uint32_t)nodes.size() - 1;
+    if (n > (size_t)kBvhLeafTris) return bb.build(0, n, 0);
+    BvhNode root = BvhBuild::dead_node();  // 0..4 triangles: a root whose only child (if any) is that leaf
+    if (n) {
+        float lo[3], hi[3];
+        bb.bounds(0, n, lo, hi);
+        root.lo[0] = make_float4(lo[0], lo[1], lo[2], BvhBuild::bits(bb.make_leaf(0, n)));
+        root.hi[0] = make_float4(hi[0], hi[1], hi[2], 0.f);
     }
-    float lo[3], hi[3];
-    const size_t before = nodes.size();
-    const uint32_t ref = bb.build(0, n, 0, lo, hi);
-    if (!(ref & kBvhLeaf)) return ref;  // the first node pushed, == before
-    (void)before;
-    BvhNode root = dead_node();  // <= 4 triangles: a root whose only child is that leaf
-    root.lo0 = make_float4(lo[0], lo[1], lo[2], BvhBuild::bits(ref));
-    root.hi0 = make_float4(hi[0], hi[1], hi[2], 0.f);
     nodes.push_back(root);
     return (uint32_t)nodes.size() - 1;
 }

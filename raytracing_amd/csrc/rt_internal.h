@@ -31,13 +31,13 @@ struct CxObject {
 
 constexpr uint32_t kNoMesh = 0xffffffffu;
 // Triangle meshes (extension): one BVH per mesh, nodes and triangles of all meshes in two flat arrays.
-// A node holds the padded boxes of its two children, so one 64-byte load decides both.  Child reference (w of the lo
-// vector, as bits): bit 31 set = leaf, bits 3..30 = first triangle, bits 0..2 = triangle count (1..4); bit 31 clear =
-// index of the child node.  A child that does not exist (single-leaf or empty mesh) has NaN bounds, which fail every
-// slab test.
+// A 4-wide node holds the padded boxes of its (up to) four children, so one 128-byte load decides all of them and the
+// chain of dependent loads per ray is half as long as in a binary tree.  Child reference (w of the lo vector, as bits):
+// bit 31 set = leaf, bits 3..30 = first triangle, bits 0..2 = triangle count (1..4); bit 31 clear = index of the child
+// node.  A child that does not exist has NaN bounds, which fail every slab test.
 struct BvhNode {
-    float4 lo0, hi0;  // child 0: padded box; lo0.w = child reference
-    float4 lo1, hi1;  // child 1
+    float4 lo[4];  // lo[i].w = child reference
+    float4 hi[4];
 };
 constexpr uint32_t kBvhLeaf = 0x80000000u;
 constexpr int kBvhLeafTris = 4;
