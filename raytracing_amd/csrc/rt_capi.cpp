@@ -252,6 +252,8 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
         if (m.n_triangles >= (1ull << 28)) return fail(RT_ERR_INVALID, "mesh " + std::to_string(mi) + ": too many triangles");
         for (uint64_t k = 0; k < m.n_triangles * 3; ++k)
             if (m.indices[k] >= m.n_vertices) return fail(RT_ERR_INVALID, "mesh " + std::to_string(mi) + ": vertex index out of range");
+        for (uint64_t k = 0; k < m.n_vertices * 3; ++k)
+            if (!std::isfinite(m.vertices[k])) return fail(RT_ERR_INVALID, "mesh " + std::to_string(mi) + ": non-finite vertex");
     }
     std::vector<rt::BvhNode> bvh_nodes;
     std::vector<rt::TriDev> tris;

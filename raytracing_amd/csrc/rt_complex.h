@@ -256,10 +256,12 @@ __device__ __forceinline__ void bvh_order(float& ta, uint32_t& ca, float& tb, ui
     ta = tl; tb = th; ca = cl; cb = ch;
 }
 
-__device__ __noinline__ bool mesh_first_hit(const DevScene& sc, uint32_t root, F3 o, F3 d, CxHit& out)
+__device__ __noinline__ bool mesh_first_hit(const DevScene& sc, uint32_t root, F3 o, F3 d, float t_limit, CxHit& out)
 {
     const float inf = __builtin_inff();
-    float best = inf;
+    // t_limit = t of the closest hit the scene scan has so far (transform.rs passes t_max through unchanged, and t is
+    // the same number in local and world space): a triangle beyond it cannot win, one exactly at it still can (key tie)
+    float best = t_limit;
     uint32_t best_id = 0xffffffffu, best_k = 0;
     const F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const F3 ro = f3(4.8e-7f * __builtin_fabsf(o.x), 4.8e-7f * __builtin_fabsf(o.y), 4.8e-7f * __builtin_fabsf(o.z));
@@ -347,11 +349,11 @@ __device__ __noinline__ bool mesh_first_hit(const DevScene& sc, uint32_t root, F
 }
 
 // hits.first() of Transform(object).intersect_all(ray, 0.001, +inf), still in the object's local space.
-__device__ __noinline__ bool cx_first_hit(const DevScene& sc, const CxObject& ob, F3 o, F3 d, CxHit& first)
+__device__ __noinline__ bool cx_first_hit(const DevScene& sc, const CxObject& ob, F3 o, F3 d, float t_limit, CxHit& first)
 {
     const F3 lo = xf_point(ob.minv, o);
     const F3 ld = xf_vector(ob.minv, d);
-    if (ob.mesh_root != kNoMesh) return mesh_first_hit(sc, ob.mesh_root, lo, ld, first);
+    if (ob.mesh_root != kNoMesh) return mesh_first_hit(sc, ob.mesh_root, lo, ld, t_limit, first);
     CxHit st[kCxStack][kCxMaxHits];
     int cnt[kCxStack];
     int sp = 0;
@@ -379,7 +381,9 @@ __device__ __forceinline__ unsigned long long cx_min_key(const DevScene& sc, F3 
 {
     for (uint32_t k = 0; k < sc.n_cx; ++k) {
         CxHit h;
-        if (cx_first_hit(sc, sc.cx_objs[k], o, d, h) && h.t < __builtin_inff()) {  // scene.rs:56; NaN / inf never win
+        const uint32_t tbits = (uint32_t)(key >> 32);  // kNoHit has all bits set: no limit yet
+        const float t_limit = tbits > 0x7f800000u ? __builtin_inff() : __uint_as_float(tbits);
+        if (cx_first_hit(sc, sc.cx_objs[k], o, d, t_limit, h) && h.t < __builtin_inff()) {  // scene.rs:56; NaN / inf never win
             unsigned long long kk = pack_key(h.t, sc.cx_objs[k].obj_id);
             if (kk < key) {
                 key = kk;

@@ -156,6 +156,20 @@ def test_unsupported_inputs_fail_loudly(engine):
     with pytest.raises(RtHipError) as e:
         engine.Scene(np.array([tree_object(8, (0, 0, 0), abi.RT_MAT_MIRROR)], dtype=abi.OBJECT_DTYPE), nodes=nodes)
     assert e.value.code == abi.RT_ERR_UNSUPPORTED
+    # meshes: index out of range, vertex index out of range, non-finite vertex, mesh shape inside a tree
+    from raytracing_amd.engine import mesh_object
+    tri = (np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]], np.uint32))
+    mobj = np.array([mesh_object(1, (0, 0, 0), abi.RT_MAT_MIRROR)], dtype=abi.OBJECT_DTYPE)
+    for objs_, meshes_ in [(mobj, [tri]), (mobj, None),
+                           (np.array([mesh_object(0, (0, 0, 0), abi.RT_MAT_MIRROR)], dtype=abi.OBJECT_DTYPE), [(tri[0], np.array([[0, 1, 3]], np.uint32))]),
+                           (np.array([mesh_object(0, (0, 0, 0), abi.RT_MAT_MIRROR)], dtype=abi.OBJECT_DTYPE), [(np.full((3, 3), np.inf, np.float32), tri[1])])]:
+        with pytest.raises(RtHipError) as e:
+            engine.Scene(objs_, meshes=meshes_)
+        assert e.value.code == abi.RT_ERR_INVALID
+    nodes = np.zeros(1, abi.NODE_DTYPE)
+    nodes[0]["shape"] = abi.RT_SHAPE_MESH
+    with pytest.raises(RtHipError):
+        engine.Scene(np.array([tree_object(0, (0, 0, 0), abi.RT_MAT_MIRROR)], dtype=abi.OBJECT_DTYPE), nodes=nodes, meshes=[tri])
 
 
 def test_half_mirror_stream_is_counter_based(engine):
