@@ -164,7 +164,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mrays/sec (primary+bounce) at 1080p 64spp",
+            "metric": "Mrays/sec (primary+bounce) at 1080p 64spp, 1/8 GPU; % of FP32 VALU peak",
             "value": value,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -181,6 +181,10 @@ def main():
                             f"max_bounces {cfg['max_bounces']}; one frame per GPU per step",
                 "segments_per_step_per_gpu": segs_per_step,
                 "sharding": "one sample block (frame) per rank; framebuffer reduce to rank 0 over RCCL" if world > 1 else "single GPU",
+                # "1/8 GPU" read both ways: value is per whole MI355X (one of a node's eight) at N=1; one XCD's share is value/8/N
+                "mrays_per_s_per_gpu": value / world,
+                "mrays_per_s_per_xcd": value / world / 8,
+                "pct_of_fp32_valu_peak": 100.0 * achieved / PEAK_FP32_TFLOPS,
             },
             "roofline": {
                 "bound": "valu_fp32",
@@ -192,7 +196,10 @@ def main():
                 "traffic": traffic,
                 "kernel_ms": kernel_ms,
                 "flop_per_segment": FLOP_PER_TEST * n_sph,
-                "note": "algorithmic 17 FLOP per ray-sphere test x spheres x segments / kernel time (HIP events on the launch stream)",
+                "note": "algorithmic 17 FLOP per ray-sphere test x spheres x segments / kernel time (HIP events on the launch stream); "
+                        "the path is FP32-VALU-bound (no MFMA by design), HBM shown for completeness",
+                "hbm": None if traffic is None else {"achieved": traffic / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                                      "frac": traffic / (kernel_ms * 1e-3) / 1e9 / 8000.0},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
