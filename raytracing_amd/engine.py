@@ -153,6 +153,11 @@ class Scene:
                                     abi.ptr(recs)))
         return pts, npts, recs
 
+    def simulate_rays_dev(self, setting, d_rays, n_rays, seed, ray_id_base, d_points, d_n_points, d_records, d_total, stream):
+        """Device-pointer variant of the hot call (ints from tensor.data_ptr(); d_records / d_total may be 0); asynchronous on `stream`."""
+        check(lib().rt_hip_simulate_dev(self._h, d_rays, n_rays, setting.as_c(), seed, ray_id_base, d_points, d_n_points,
+                                        d_records or None, d_total or None, stream))
+
     def render(self, gen, spp, setting, seed=0, cell_begin=0, cell_count=None, cell_step=1):
         """Generator-driven loop: per-cell framebuffer + first-hit ids/t + segment counts (host buffers)."""
         if cell_count is None:

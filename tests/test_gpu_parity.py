@@ -470,3 +470,29 @@ def test_triangle_meshes_bvh_equals_brute_force(engine):
     for a, b in zip(got[:4], want[:4]):
         assert same(a, b)
     assert got[4] == want[4] and (got[1] == 0).sum() > 50  # the mesh (object 0) is what most primary rays hit
+
+
+def test_device_pointer_entry_points_match_host_ones(engine):
+    """rt_hip_simulate_dev / rt_hip_render_dev (device buffers, caller's stream) against the host-buffer entry points."""
+    import torch
+
+    objs = random_scene(150, 2, seed=9)
+    rays = random_rays(5000, seed=4)
+    sc = engine.Scene(objs)
+    st = SimulationSettingsConfig(40.0, 7)
+    pts, npts, recs = sc.simulate_rays_raw(st, rays=rays, seed=5, ray_id_base=77)
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        d_rays = torch.from_numpy(rays.view(np.uint8).reshape(len(rays), -1)).to(dev)
+        d_pts = torch.zeros((len(rays), 8, 3), dtype=torch.float32, device=dev)
+        d_np = torch.zeros(len(rays), dtype=torch.int32, device=dev)
+        d_rec = torch.zeros((len(rays), 7, abi.RECORD_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        d_tot = torch.zeros(1, dtype=torch.int64, device=dev)
+        sc.simulate_rays_dev(st, d_rays.data_ptr(), len(rays), 5, 77, d_pts.data_ptr(), d_np.data_ptr(), d_rec.data_ptr(), d_tot.data_ptr(),
+                             side.cuda_stream)
+    side.synchronize()
+    assert np.array_equal(d_np.cpu().numpy().astype(np.uint32), npts)
+    assert same(d_pts.cpu().numpy(), pts)
+    assert_records_equal(d_rec.cpu().numpy().view(abi.RECORD_DTYPE).reshape(recs.shape), recs, "simulate_dev")
+    assert int(d_tot.item()) == int((npts - 1).sum())  # one segment per bounce-loop iteration
