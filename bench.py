@@ -66,12 +66,17 @@ def main():
     from raytracing_amd.engine import SimulationSettingsConfig
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # RT_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, reduce) even with one rank, to rehearse it on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # Rehearsal knob for a 1-GPU box: all ranks share device 0 and the collective runs over gloo on host copies.
     rehearsal = os.environ.get("RT_BENCH_SINGLE_DEVICE") == "1"
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if rehearsal:
             local_rank = 0
             torch.cuda.set_device(0)
@@ -84,11 +89,13 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     def reduce_fb(t):
+        """Sum the ranks' framebuffers to rank 0.  Over RCCL the reduce is asynchronous (RCCL's own stream, ordered after the
+        render that filled `t`), so it overlaps the next frame's render into the other buffer; returns the work handle."""
         if rehearsal:
             h = t.cpu()
             dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
-        else:
-            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+            return None
+        return dist.reduce(t, dst=0, op=dist.ReduceOp.SUM, async_op=True)
 
     def allreduce_scalar(t, op):
         if rehearsal:
@@ -106,22 +113,39 @@ def main():
     st = SimulationSettingsConfig(cfg["infinity_distance"], cfg["max_bounces"])
     n_cells = args.width * args.height
     # inputs (scene, generator constants) and outputs resident in HBM before the timed region
-    fb = torch.empty((n_cells, 3), dtype=torch.float32, device=dev)
+    fbs = [torch.empty((n_cells, 3), dtype=torch.float32, device=dev) for _ in range(2 if use_dist else 1)]  # double-buffered for the reduce
+    pending = [None, None]
     first_id = torch.empty(n_cells, dtype=torch.int32, device=dev)
     first_t = torch.empty(n_cells, dtype=torch.float32, device=dev)
     seg = torch.empty(n_cells, dtype=torch.int32, device=dev)
     total = torch.zeros(1, dtype=torch.int64, device=dev)
     seed = (cfg["seed"] + rank * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF  # rank = sample block
 
-    def step():
+    frame = [0]
+
+    def step(events=None):
+        b = frame[0] % len(fbs)
+        frame[0] += 1
+        if pending[b] is not None:  # the reduce that last read this buffer must be done before it is overwritten
+            pending[b].wait()
+            pending[b] = None
+        fb = fbs[b]
+        if events:
+            events[0].record()
         stream = torch.cuda.current_stream().cuda_stream
         scene.render_dev(cfg["gen"], cfg["spp"], st, seed, 0, n_cells, 1, fb.data_ptr(), first_id.data_ptr(), first_t.data_ptr(),
                          seg.data_ptr(), total.data_ptr(), stream)
-        if world > 1:
-            reduce_fb(fb)
+        if events:
+            events[1].record()
+        if use_dist:
+            pending[b] = reduce_fb(fb)
 
     def barrier():
-        if world > 1:
+        for b in range(len(pending)):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -133,13 +157,7 @@ def main():
     segs_done = 0
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()
-        stream = torch.cuda.current_stream().cuda_stream
-        scene.render_dev(cfg["gen"], cfg["spp"], st, seed, 0, n_cells, 1, fb.data_ptr(), first_id.data_ptr(), first_t.data_ptr(),
-                         seg.data_ptr(), total.data_ptr(), stream)
-        ev[k][1].record()
-        if world > 1:
-            reduce_fb(fb)
+        step(ev[k])
     barrier()
     elapsed = time.perf_counter() - t0
     segs_per_step = int(total.item())
@@ -147,7 +165,7 @@ def main():
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     s = torch.tensor([segs_per_step], dtype=torch.int64, device=dev)
-    if world > 1:
+    if use_dist:
         allreduce_scalar(t, dist.ReduceOp.MAX)
         allreduce_scalar(s, dist.ReduceOp.SUM)
     elapsed_max = float(t.item())
@@ -180,7 +198,7 @@ def main():
                 "workload": f"C2: {n_sph} spheres (seed 0xC0FFEE), Projector {args.width}x{args.height} cells, {cfg['spp']} spp, "
                             f"max_bounces {cfg['max_bounces']}; one frame per GPU per step",
                 "segments_per_step_per_gpu": segs_per_step,
-                "sharding": "one sample block (frame) per rank; framebuffer reduce to rank 0 over RCCL" if world > 1 else "single GPU",
+                "sharding": "one sample block (frame) per rank; framebuffer reduce to rank 0 over RCCL, overlapped with the next frame" if world > 1 else "single GPU",
                 # "1/8 GPU" read both ways: value is per whole MI355X (one of a node's eight) at N=1; one XCD's share is value/8/N
                 "mrays_per_s_per_gpu": value / world,
                 "mrays_per_s_per_xcd": value / world / 8,
@@ -205,7 +223,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, n_sph)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
