@@ -52,3 +52,25 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in text and not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/rt_hip.h is the drop-in boundary: it must compile as C99 (no C++-isms, no torch / HIP types) and a C program
+    that only declares use of every entry point must link against the shared library."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use.c"
+    from raytracing_amd._lib import EXPORTS
+
+    body = "\n".join(f"    p[{k}] = (fn){name};" for k, name in enumerate(EXPORTS))
+    src.write_text('#include "rt_hip.h"\n#include <stdio.h>\ntypedef void (*fn)(void);\nint main(void) {\n    fn p[%d];\n%s\n'
+                   '    printf("%%d %%d %%d\\n", (int)sizeof(RtObject), (int)sizeof(RtRay), (int)sizeof(RtBounceRecord));\n    return p[0] == 0;\n}\n'
+                   % (len(EXPORTS), body))
+    exe = tmp_path / "use"
+    libdir = os.path.join(root, "raytracing_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-lrt_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.split() == ["44", "28", "52"], (out.stdout, out.stderr)
