@@ -373,6 +373,7 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     d.n_pl = (uint32_t)pl_pos.size();
     d.n_obj = (uint32_t)n_objects;
     d.n_cx = (uint32_t)cx_objs.size();
+    d.n_bvh_nodes = (uint32_t)bvh_nodes.size();
     d.c2max = c2max_f;
     s->host_spheres.assign(sph_exact.begin(), sph_exact.begin() + n_sph);
     *out_scene = s;

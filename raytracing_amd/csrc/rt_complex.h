@@ -256,7 +256,16 @@ __device__ __forceinline__ void bvh_order(float& ta, uint32_t& ca, float& tb, ui
     ta = tl; tb = th; ca = cl; cb = ch;
 }
 
-__device__ __noinline__ bool mesh_first_hit(const DevScene& sc, uint32_t root, F3 o, F3 d, float t_limit, CxHit& out)
+// LDS copy of the first nodes of sc.bvh_nodes (the tree tops: the builder numbers nodes breadth first), as float4[8] per node.
+typedef float V4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const V4f LdsF4;
+__device__ __forceinline__ float4 lds_f4(LdsF4* q) { const V4f v = *q; return make_float4(v.x, v.y, v.z, v.w); }
+struct BvhLds {
+    LdsF4* nodes;
+    uint32_t count;
+};
+
+__device__ __noinline__ bool mesh_first_hit(const DevScene& sc, BvhLds top, uint32_t root, F3 o, F3 d, float t_limit, CxHit& out)
 {
     const float inf = __builtin_inff();
     // t_limit = t of the closest hit the scene scan has so far (transform.rs passes t_max through unchanged, and t is
@@ -275,7 +284,17 @@ __device__ __noinline__ bool mesh_first_hit(const DevScene& sc, uint32_t root, F
     // triangle code runs with as many lanes as possible
     while (cur != kDone) {
         while (!(cur & kBvhLeaf) && cur != kDone) {
-            const BvhNode n = sc.bvh_nodes[cur];
+            BvhNode n;
+            if (cur < top.count) {  // every ray passes through these: LDS answers in a fraction of an L1 round trip
+                LdsF4* q = top.nodes + cur * 8u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    n.lo[i] = lds_f4(q + i);
+                    n.hi[i] = lds_f4(q + 4 + i);
+                }
+            } else {
+                n = sc.bvh_nodes[cur];
+            }
             float t0 = bvh_child_entry(n.lo[0], n.hi[0], o_lo, o_hi, inv, best), t1 = bvh_child_entry(n.lo[1], n.hi[1], o_lo, o_hi, inv, best);
             float t2 = bvh_child_entry(n.lo[2], n.hi[2], o_lo, o_hi, inv, best), t3 = bvh_child_entry(n.lo[3], n.hi[3], o_lo, o_hi, inv, best);
             uint32_t c0 = __float_as_uint(n.lo[0].w), c1 = __float_as_uint(n.lo[1].w), c2 = __float_as_uint(n.lo[2].w), c3 = __float_as_uint(n.lo[3].w);
@@ -349,11 +368,11 @@ __device__ __noinline__ bool mesh_first_hit(const DevScene& sc, uint32_t root, F
 }
 
 // hits.first() of Transform(object).intersect_all(ray, 0.001, +inf), still in the object's local space.
-__device__ __noinline__ bool cx_first_hit(const DevScene& sc, const CxObject& ob, F3 o, F3 d, float t_limit, CxHit& first)
+__device__ __noinline__ bool cx_first_hit(const DevScene& sc, BvhLds top, const CxObject& ob, F3 o, F3 d, float t_limit, CxHit& first)
 {
     const F3 lo = xf_point(ob.minv, o);
     const F3 ld = xf_vector(ob.minv, d);
-    if (ob.mesh_root != kNoMesh) return mesh_first_hit(sc, ob.mesh_root, lo, ld, t_limit, first);
+    if (ob.mesh_root != kNoMesh) return mesh_first_hit(sc, top, ob.mesh_root, lo, ld, t_limit, first);
     CxHit st[kCxStack][kCxMaxHits];
     int cnt[kCxStack];
     int sp = 0;
@@ -377,13 +396,13 @@ __device__ __noinline__ bool cx_first_hit(const DevScene& sc, const CxObject& ob
 }
 
 // Merge every complex object into the running closest-hit key; remember the winner's local hit record.
-__device__ __forceinline__ unsigned long long cx_min_key(const DevScene& sc, F3 o, F3 d, unsigned long long key, CxHit& best, int& best_cx)
+__device__ __forceinline__ unsigned long long cx_min_key(const DevScene& sc, BvhLds top, F3 o, F3 d, unsigned long long key, CxHit& best, int& best_cx)
 {
     for (uint32_t k = 0; k < sc.n_cx; ++k) {
         CxHit h;
         const uint32_t tbits = (uint32_t)(key >> 32);  // kNoHit has all bits set: no limit yet
         const float t_limit = tbits > 0x7f800000u ? __builtin_inff() : __uint_as_float(tbits);
-        if (cx_first_hit(sc, sc.cx_objs[k], o, d, t_limit, h) && h.t < __builtin_inff()) {  // scene.rs:56; NaN / inf never win
+        if (cx_first_hit(sc, top, sc.cx_objs[k], o, d, t_limit, h) && h.t < __builtin_inff()) {  // scene.rs:56; NaN / inf never win
             unsigned long long kk = pack_key(h.t, sc.cx_objs[k].obj_id);
             if (kk < key) {
                 key = kk;

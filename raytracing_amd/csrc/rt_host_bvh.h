@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <numeric>
 #include <vector>
@@ -20,7 +21,6 @@ struct BvhBuild {
     const RtMesh& m;
     std::vector<uint32_t> order;  // triangle permutation of this mesh
     std::vector<float> cx, cy, cz;
-    int max_depth = 0;
 
     static float bits(uint32_t u)
     {
@@ -102,31 +102,49 @@ struct BvhBuild {
         return mid;
     }
 
-    // Builds the node of order[b, e) (more than one leaf's worth): two levels of median splits give up to four parts;
-    // a part that fits a leaf becomes one, the others recurse.  Each level quarters the range: depth <= 14 for 2^28.
-    uint32_t build(size_t b, size_t e, int depth)
+    // Builds the tree of order[0, n) (more than one leaf's worth), breadth first so that the top levels — the nodes every
+    // ray reads — sit at the front of the array, where the render kernel's LDS copy takes them from.  Per node two levels
+    // of median splits give up to four parts; a part that fits a leaf becomes one, the others are queued.  Each level
+    // quarters the range: depth <= 14 for the 2^28 triangles allowed.
+    uint32_t build_all(size_t n)
     {
-        max_depth = std::max(max_depth, depth);
-        const uint32_t self = (uint32_t)nodes.size();
+        struct Job {
+            uint32_t self;
+            size_t b, e;
+        };
+        std::deque<Job> todo;
+        const uint32_t root = (uint32_t)nodes.size();
         nodes.push_back(BvhNode{});
-        size_t cut[5];
-        int parts = 0;
-        const size_t mid = split(b, e);
-        cut[parts++] = b;
-        if (mid - b > (size_t)kBvhLeafTris) cut[parts++] = split(b, mid);
-        cut[parts++] = mid;
-        if (e - mid > (size_t)kBvhLeafTris) cut[parts++] = split(mid, e);
-        cut[parts] = e;
-        BvhNode n = dead_node();
-        for (int i = 0; i < parts; ++i) {
-            float lo[3], hi[3];
-            bounds(cut[i], cut[i + 1], lo, hi);
-            const uint32_t ref = cut[i + 1] - cut[i] <= (size_t)kBvhLeafTris ? make_leaf(cut[i], cut[i + 1]) : build(cut[i], cut[i + 1], depth + 1);
-            n.lo[i] = make_float4(lo[0], lo[1], lo[2], bits(ref));
-            n.hi[i] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        todo.push_back({root, 0, n});
+        while (!todo.empty()) {
+            const Job j = todo.front();
+            todo.pop_front();
+            size_t cut[5];
+            int parts = 0;
+            const size_t mid = split(j.b, j.e);
+            cut[parts++] = j.b;
+            if (mid - j.b > (size_t)kBvhLeafTris) cut[parts++] = split(j.b, mid);
+            cut[parts++] = mid;
+            if (j.e - mid > (size_t)kBvhLeafTris) cut[parts++] = split(mid, j.e);
+            cut[parts] = j.e;
+            BvhNode nd = dead_node();
+            for (int i = 0; i < parts; ++i) {
+                float lo[3], hi[3];
+                bounds(cut[i], cut[i + 1], lo, hi);
+                uint32_t ref;
+                if (cut[i + 1] - cut[i] <= (size_t)kBvhLeafTris) {
+                    ref = make_leaf(cut[i], cut[i + 1]);
+                } else {
+                    ref = (uint32_t)nodes.size();
+                    nodes.push_back(BvhNode{});
+                    todo.push_back({ref, cut[i], cut[i + 1]});
+                }
+                nd.lo[i] = make_float4(lo[0], lo[1], lo[2], bits(ref));
+                nd.hi[i] = make_float4(hi[0], hi[1], hi[2], 0.f);
+            }
+            nodes[j.self] = nd;
         }
-        nodes[self] = n;
-        return self;
+        return root;
     }
 
     // A node none of whose children can be hit (NaN bounds): the root of an empty mesh, and the blank every node starts from.
@@ -155,7 +173,7 @@ inline uint32_t build_mesh_bvh(const RtMesh& m, std::vector<BvhNode>& nodes, std
         bb.cy[t] = (a[1] + b[1] + c[1]) * (1.0f / 3.0f);
         bb.cz[t] = (a[2] + b[2] + c[2]) * (1.0f / 3.0f);
     }
-    if (n > (size_t)kBvhLeafTris) return bb.build(0, n, 0);
+    if (n > (size_t)kBvhLeafTris) return bb.build_all(n);
     BvhNode root = BvhBuild::dead_node();  // 0..4 triangles: a root whose only child (if any) is that leaf
     if (n) {
         float lo[3], hi[3];

@@ -47,6 +47,7 @@ struct TriDev {
     float4 e2;  // v2 - v0 (f32)
 };
 constexpr int kBvhStack = 64;
+constexpr uint32_t kBvhLdsNodes = 85;  // 1 + 4 + 16 + 64: the top four levels of a 4-wide tree, 10,880 bytes
 
 // Flattened scene as the kernels see it (all pointers are device memory).
 struct DevScene {
@@ -65,6 +66,7 @@ struct DevScene {
     const BvhNode* bvh_nodes;   // all meshes
     const TriDev* tris;         // all meshes, BVH leaf order
     uint32_t n_cx;
+    uint32_t n_bvh_nodes;  // entries of bvh_nodes
     uint32_t n_sph, n_sph_pad, n_pl, n_obj;
     float c2max;  // >= max_j (|p_j|^2 + r_j^2), rounded up: magnitude bound used by the cull margin
 };
@@ -103,6 +105,7 @@ struct TraceParams {
     uint32_t* secq;     // per-wave rings of continuing rays: [grid waves][kSecFields][kSecCap] dwords
     float prim_margin;  // >= 64 u * max_j(|p_j - O|^2 + r_j^2): margin of the shared-origin filter
     float4* prim_table; // streamed mode only: [n_sph_pad] {p - O, sK}, rebuilt per launch
+    uint32_t bvh_lds_nodes;  // pinhole kernel: the first this-many BvhNodes are copied into LDS (set by launch_pinhole)
 };
 
 constexpr unsigned kSecCap = 256;    // entries per wave ring (a primary step adds <= 128 to a residue < 128)

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             if (CX) {
                 CxHit ch;
                 int ci = -1;
-                key = cx_min_key(sc, o, d, key, ch, ci);
+                key = cx_min_key(sc, BvhLds{nullptr, 0u}, o, d, key, ch, ci);  // no LDS tree top in this kernel
                 if (ci >= 0) {
                     pre.valid = true;
                     pre.front = ch.ff != 0;

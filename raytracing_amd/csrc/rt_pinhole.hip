@@ -62,8 +62,15 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
             tiles[k] = sc.sph_cull[k];
             tiles[n_pad + k] = pinhole_entry(sc, k, O, p.prim_margin);
         }
-        __syncthreads();
     }
+    // triangle meshes: the top of the BVH (first nodes of the breadth-first array) sits behind the tables
+    float4* bvh_top = tiles + (STREAM ? 0u : 2u * n_pad);
+    if (CX) {
+        const float4* src = reinterpret_cast<const float4*>(sc.bvh_nodes);
+        for (unsigned k = threadIdx.x; k < p.bvh_lds_nodes * 8u; k += kPinThreads) bvh_top[k] = src[k];
+    }
+    const BvhLds top{(LdsF4*)bvh_top, CX ? p.bvh_lds_nodes : 0u};
+    if (!STREAM || CX) __syncthreads();
 
     // per-wave ring of continuing rays (global memory, only this wave touches it)
     const unsigned gwave = blockIdx.x * (kPinThreads / 64) + wave;
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 if (CX) {
                     CxHit ch;
                     int ci = -1;
-                    key = cx_min_key(sc, ro[r], rd[r], key, ch, ci);
+                    key = cx_min_key(sc, top, ro[r], rd[r], key, ch, ci);
                     if (ci >= 0) {
                         pre.valid = true;
                         pre.front = ch.ff != 0;
@@ -296,7 +303,21 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
 constexpr int kR = 2;
 
 inline bool stream_mode(const TraceParams& p) { return p.sc.n_sph_pad > (uint32_t)kTileSpheres; }
-inline size_t dyn_lds(const TraceParams& p) { return stream_mode(p) ? 0 : (size_t)p.sc.n_sph_pad * sizeof(float4) * 2; }
+inline size_t table_lds(const TraceParams& p) { return stream_mode(p) ? 0 : (size_t)p.sc.n_sph_pad * sizeof(float4) * 2; }
+constexpr size_t kLdsPerBlock = 80 * 1024;  // two 512-thread blocks per CU share 160 KB
+inline size_t dyn_lds(const TraceParams& p) { return table_lds(p) + (size_t)p.bvh_lds_nodes * sizeof(BvhNode); }
+
+// How many tree-top nodes fit beside the kernel's static LDS and the sphere tables without costing a block per CU.
+template <bool STREAM>
+uint32_t bvh_lds_fit(const TraceParams& p)
+{
+    hipFuncAttributes fa{};
+    if (hipFuncGetAttributes(&fa, (const void*)pinhole_kernel<2, STREAM, true>) != hipSuccess) return 0;
+    const size_t used = fa.sharedSizeBytes + table_lds(p) + 512;
+    const size_t room = used < kLdsPerBlock ? (kLdsPerBlock - used) / sizeof(BvhNode) : 0;
+    uint32_t n = p.sc.n_bvh_nodes < kBvhLdsNodes ? p.sc.n_bvh_nodes : kBvhLdsNodes;
+    return room < n ? (uint32_t)room : n;
+}
 
 template <bool STREAM, bool CX>
 int pinhole_blocks_per_cu(size_t dyn_bytes)
@@ -333,22 +354,27 @@ size_t pinhole_secq_bytes(const TraceParams& p, int n_cu)
 size_t pinhole_table_bytes(const TraceParams& p) { return stream_mode(p) ? (size_t)p.sc.n_sph_pad * sizeof(float4) : 0; }
 
 template <bool CX>
-static hipError_t launch_pinhole_t(const TraceParams& p, int n_cu, hipStream_t stream)
+static hipError_t launch_pinhole_t(const TraceParams& p_in, int n_cu, hipStream_t stream)
 {
+    TraceParams p = p_in;
+    p.bvh_lds_nodes = CX ? (stream_mode(p) ? bvh_lds_fit<true>(p) : bvh_lds_fit<false>(p)) : 0;
     const unsigned grid = pinhole_grid(p, n_cu);
+    static bool attr_set = false;  // per instantiation; one device per process (rt_hip_init)
+    if (!attr_set) {
+        const int max_dyn = (int)(kTileSpheres * sizeof(float4) * 2 + kBvhLdsNodes * sizeof(BvhNode));
+        hipError_t e = hipFuncSetAttribute((const void*)pinhole_kernel<kR, false, CX>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)pinhole_kernel<kR, true, CX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kBvhLdsNodes * sizeof(BvhNode)));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     if (stream_mode(p)) {
         hipLaunchKernelGGL(pinhole_table_kernel, dim3((p.sc.n_sph_pad + 255) / 256), dim3(256), 0, stream, p, p.prim_table);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((pinhole_kernel<kR, true, CX>), dim3(grid), dim3(kPinThreads), 0, stream, p);
+        hipLaunchKernelGGL((pinhole_kernel<kR, true, CX>), dim3(grid), dim3(kPinThreads), dyn_lds(p), stream, p);
         return hipGetLastError();
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)pinhole_kernel<kR, false, CX>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(kTileSpheres * sizeof(float4) * 2));
-        if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL((pinhole_kernel<kR, false, CX>), dim3(grid), dim3(kPinThreads), dyn_lds(p), stream, p);
     return hipGetLastError();
