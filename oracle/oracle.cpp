@@ -845,9 +845,10 @@ static void render_range(const orc_scene* s, const RtRayGenerator* gen, uint32_t
                 if (first_t) first_t[m] = st.max_bounces ? recs[0].t : std::numeric_limits<float>::infinity();
             }
             V3 val = esc ? sky(fd) : v3(0, 0, 0);
-            accx += (uint64_t)std::llrintf(val.x * 16777216.0f);
-            accy += (uint64_t)std::llrintf(val.y * 16777216.0f);
-            accz += (uint64_t)std::llrintf(val.z * 16777216.0f);
+            auto q = [](float v) { return v == v ? (uint64_t)std::llrintf(v * 16777216.0f) : (uint64_t)0; };  // NaN path value -> 0
+            accx += q(val.x);
+            accy += q(val.y);
+            accz += q(val.z);
         }
         const double denom = (double)spp * 16777216.0;
         fb[m * 3 + 0] = (float)((double)accx / denom);

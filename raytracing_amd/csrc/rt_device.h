@@ -398,7 +398,9 @@ __device__ __forceinline__ Shade shade_hit(const DevScene& sc, F3 o, F3 d, float
     return h;
 }
 
-__device__ __forceinline__ unsigned long long quantize(float v) { return (unsigned long long)__float2ll_rn(v * 16777216.0f); }
+// q = rint(v * 2^24); a NaN value (a path the reference's own arithmetic turned into NaN, e.g. a ray that
+// started inside a Box, axis_aligned_box.rs:70-95) contributes 0.
+__device__ __forceinline__ unsigned long long quantize(float v) { return v == v ? (unsigned long long)__float2ll_rn(v * 16777216.0f) : 0ull; }
 
 }  // namespace
 }  // namespace rt

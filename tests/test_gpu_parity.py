@@ -496,3 +496,39 @@ def test_device_pointer_entry_points_match_host_ones(engine):
     assert same(d_pts.cpu().numpy(), pts)
     assert_records_equal(d_rec.cpu().numpy().view(abi.RECORD_DTYPE).reshape(recs.shape), recs, "simulate_dev")
     assert int(d_tot.item()) == int((npts - 1).sum())  # one segment per bounce-loop iteration
+
+
+def test_streamed_tables_with_meshes_and_csg(engine):
+    """The four kernel variants that carry the per-lane object path — {LDS tables, streamed tables} x {pinhole, general} — on
+    one scene: 1,100 spheres (above the LDS tile), two planes, a mesh (LDS tree top in the pinhole kernel), a rotated
+    box and a lens, through Projector, ParallelGrid and explicit rays; then the same objects with 200 spheres."""
+    from raytracing_amd.engine import mesh_object, shape_object
+
+    hf = synth.heightfield_mesh(24, 24, extent=(50.0, 50.0), amplitude=4.0)
+    for n_spheres in (1100, 200):
+        objs = list(random_scene(n_spheres, 2, seed=21, extent=(60.0, 30.0, 60.0)))
+        objs.insert(5, mesh_object(0, (0, -25, 0), abi.RT_MAT_MIRROR, rotation_y_deg=12.0))
+        objs.insert(40, shape_object(abi.RT_SHAPE_BOX, (8.0, 8.0, 8.0), (10, 5, -80), abi.RT_MAT_GLASS, 1.5, rotation_y_deg=30.0))
+        objs.append(shape_object(abi.RT_SHAPE_LENS, (2.0, 10.0, 12.0, 12.0), (-15, 0, -85), abi.RT_MAT_GLASS, 1.5))
+        objs = np.array(objs, dtype=abi.OBJECT_DTYPE)
+        sc = engine.Scene(objs, meshes=[hf])
+        osc = ob.OracleScene(objs, meshes=[hf])
+        st = SimulationSettingsConfig(60.0, 6)
+        gen = projector((0.0, 10.0, -150.0), (-70.0, -50.0, -70.0), (140.0, 0.0, 0.0), (0.0, 80.0, 0.0), 40, 28)
+        got = sc.render(gen, 3, st, seed=9)
+        want = osc.render(gen, 3, 60.0, 6, seed=9, threads=8)
+        for a, b in zip(got[:4], want[:4]):
+            assert same(a, b)
+        assert got[4] == want[4]
+        first = set(np.unique(got[1]).tolist())
+        assert 5 in first and (40 in first or len(objs) - 1 in first)  # the mesh and a CSG object are primary hits somewhere
+        gen2 = parallel_grid((-60, -30, -120), (120, 0, 0), (0, 60, 0), 30, 20, (0.02, -0.1, 1.0))
+        got = sc.render(gen2, 2, st, seed=9)
+        want = osc.render(gen2, 2, 60.0, 6, seed=9, threads=8)
+        for a, b in zip(got[:4], want[:4]):
+            assert same(a, b)
+        rays = random_rays(3000, seed=8, extent=(70.0, 35.0, 70.0))
+        pts, npts, recs = sc.simulate_rays_raw(st, rays=rays, seed=4)
+        opts, onpts, orecs, _ = osc.simulate(rays, 60.0, 6, seed=4)
+        assert np.array_equal(npts, onpts) and same(pts, opts)
+        assert_records_equal(recs, orecs, f"mixed-{n_spheres}")
