@@ -150,3 +150,19 @@ def test_frame_sequence_native_python_oracle(tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "frame.pfm").read_bytes() == (out_n / names[2]).read_bytes()
+
+
+def test_obj_mesh_reader(tmp_path):
+    from raytracing_amd import meshio, synth
+
+    p = tmp_path / "quad.obj"
+    p.write_text("# a quad and a triangle\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 0.5 2\nf 1 2 3 4\nf -1/1/1 1/2/2 2/3/3  # relative index\n")
+    v, idx = meshio.load_obj(p)
+    assert v.shape == (5, 3) and v.dtype == np.float32 and idx.tolist() == [[0, 1, 2], [0, 2, 3], [4, 0, 1]]
+    hv, hi = synth.heightfield_mesh(6, 5)
+    meshio.save_obj(tmp_path / "hf.obj", hv, hi)
+    bv, bi = meshio.load_obj(tmp_path / "hf.obj")
+    assert np.array_equal(bv, hv) and np.array_equal(bi, hi)  # repr() of an f32 widened to f64 round-trips exactly
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nf 1 2 3\n")
+    with pytest.raises(ValueError):
+        meshio.load_obj(tmp_path / "bad.obj")
