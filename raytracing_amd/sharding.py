@@ -44,3 +44,86 @@ def gather_image(local, rank, world, n_cells, dist, dst=None):
     out = torch.empty((world * cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return interleave_shards(out.reshape((world, cap) + tuple(local.shape[1:])), n_cells)
+
+
+def render_sharded(scene, gen, spp, setting, seed, rank, world, dist, device, max_cells_per_launch=1 << 19):
+    """One frame over `world` GPUs: this rank renders cells rank, rank+world, ... (in launches of at most
+    `max_cells_per_launch` cells), then one all-gather assembles the image on every rank.
+    Returns (fb [n_cells, 3] float32 torch tensor in cell order, this rank's ray-segment count)."""
+    import torch
+
+    n_cells = gen.count_u * gen.count_v
+    begin, count, step = cell_shard(rank, world, n_cells)
+    cap = shard_capacity(world, n_cells)
+    fb = torch.zeros((cap, 3), dtype=torch.float32, device=device)
+    total = torch.zeros(1, dtype=torch.int64, device=device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    segments, done = 0, 0
+    while done < count:
+        n = min(max_cells_per_launch, count - done)
+        scene.render_dev(gen, spp, setting, seed, begin + done * step, n, step, fb[done:].data_ptr(), 0, 0, 0, total.data_ptr(), stream)
+        segments += int(total.item())  # also orders the launches: the library's scratch is shared between calls
+        done += n
+    if world > 1:
+        return gather_image(fb, rank, world, n_cells, dist), segments
+    return fb[:n_cells], segments
+
+
+def main(argv=None):
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m raytracing_amd.sharding
+           --workload c4 [--width 3840 --height 2160 --spp 1024] [--out frame.pfm]
+    BASELINE.json configs[3]: the 10,000-sphere frame tile-sharded over N GPUs, framebuffer gathered over RCCL."""
+    import argparse
+    import os
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from . import engine, synth
+    from .engine import SimulationSettingsConfig
+    from .image import write_pfm
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["c2", "c4"], default="c4")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args(argv)
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    engine.init(local)
+    make = synth.config_c4 if a.workload == "c4" else synth.config_c2
+    w, h = (a.width or (3840 if a.workload == "c4" else 1920)), (a.height or (2160 if a.workload == "c4" else 1080))
+    cfg = make(w, h)
+    spp = a.spp or (1024 if a.workload == "c4" else 64)
+    scene = engine.Scene(cfg["objects"])
+    st = SimulationSettingsConfig(cfg["infinity_distance"], cfg["max_bounces"])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fb, segs = render_sharded(scene, cfg["gen"], spp, st, cfg["seed"], rank, world, dist, dev)
+    seg_t = torch.tensor([segs], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(seg_t)
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        total = int(seg_t.item())
+        print(f"{a.workload} {w}x{h} x {spp} spp on {world} GPU(s): {total} segments in {dt:.3f} s = {total / dt / 1e6:.0f} Mrays/s; "
+              f"fb checksum {fb.sum(0, dtype=torch.float64).tolist()}", flush=True)
+        if a.out:
+            write_pfm(a.out, fb.cpu().numpy(), w, h)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -532,3 +532,44 @@ def test_streamed_tables_with_meshes_and_csg(engine):
         opts, onpts, orecs, _ = osc.simulate(rays, 60.0, 6, seed=4)
         assert np.array_equal(npts, onpts) and same(pts, opts)
         assert_records_equal(recs, orecs, f"mixed-{n_spheres}")
+
+
+def test_render_sharded_assembles_the_single_gpu_image(engine):
+    """sharding.render_sharded as each of 3 ranks would run it (several launches per rank), shards interleaved as the
+    all-gather would: bit-identical to one full-frame render.  (The collective itself is covered by the gloo test.)"""
+    import torch
+
+    from raytracing_amd import sharding
+
+    cfg = synth.config_c2(50, 31)
+    sc = engine.Scene(cfg["objects"])
+    st = SimulationSettingsConfig(cfg["infinity_distance"], cfg["max_bounces"])
+    full = sc.render(cfg["gen"], 5, st, seed=3)
+    n, world = 50 * 31, 3
+    dev = torch.device("cuda", 0)
+    shards, segs = [], 0
+    for rank in range(world):
+        fb, s_ = _render_rank(sc, cfg, st, rank, world, dev)
+        shards.append(fb)
+        segs += s_
+    got = sharding.interleave_shards(torch.stack(shards), n).cpu().numpy()
+    assert np.array_equal(got, full[0]) and segs == full[4]
+    one, s1 = sharding.render_sharded(sc, cfg["gen"], 5, st, 3, 0, 1, None, dev, max_cells_per_launch=300)
+    assert np.array_equal(one.cpu().numpy(), full[0]) and s1 == full[4]
+
+
+def _render_rank(sc, cfg, st, rank, world, dev):
+    """render_sharded's local part for one rank of `world` (no process group here): its padded shard and segment count."""
+    import torch
+
+    from raytracing_amd import sharding
+
+    class NoGather:  # stands in for torch.distributed: hands the local shard back
+        pass
+
+    orig = sharding.gather_image
+    sharding.gather_image = lambda local, r, w, n, dist: local
+    try:
+        return sharding.render_sharded(sc, cfg["gen"], 5, st, 3, rank, world, NoGather(), dev, max_cells_per_launch=200)
+    finally:
+        sharding.gather_image = orig
