@@ -8,7 +8,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+LIB_PATH = os.environ.get("RT_HIP_LIBRARY") or os.path.join(_HERE, "librt_hip.so")  # RT_HIP_LIBRARY: explicit path (A/B builds)
 _LIB = None
 
 # every symbol include/rt_hip.h declares

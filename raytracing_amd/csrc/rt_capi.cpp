@@ -129,6 +129,29 @@ bool use_pinhole(const rt::TraceParams& p)
     return !p.rays && p.gen.kind == RT_GEN_PROJECTOR && p.scan_mode == 0 && p.fb_q != nullptr;
 }
 
+// Rounding budget of the shared-origin filter's affine numerator: rho = (3G + 7M) / d_min, with
+// G = |corner - O| + |u| + |v|, M = |corner| + |u| + |v| + |O| and d_min = distance from O to the target plane (a lower
+// bound of every |target - O|).  Not finite (plane through O, degenerate parallelogram) => the general kernel runs instead.
+double pinhole_rho(const rt::DevGen& g)
+{
+    auto norm = [](const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    double O[3], c[3], co[3], u[3], v[3], n[3];
+    for (int k = 0; k < 3; ++k) {
+        O[k] = g.a[k];
+        c[k] = g.corner[k];
+        co[k] = c[k] - O[k];
+        u[k] = (double)g.u_step[k] * g.count_u;
+        v[k] = (double)g.v_step[k] * g.count_v;
+    }
+    n[0] = u[1] * v[2] - u[2] * v[1];
+    n[1] = u[2] * v[0] - u[0] * v[2];
+    n[2] = u[0] * v[1] - u[1] * v[0];
+    const double nn = norm(n);
+    const double dmin = std::fabs(co[0] * n[0] + co[1] * n[1] + co[2] * n[2]) / nn;
+    const double G = norm(co) + norm(u) + norm(v), M = norm(c) + norm(u) + norm(v) + norm(O);
+    return (3.0 * G + 7.0 * M) / dmin;  // NaN / inf when nn == 0 or dmin == 0
+}
+
 int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream, const rt_scene* scene)
 {
     unsigned idx = g_ctx.next_counter++ % kCounterRing;
@@ -136,7 +159,13 @@ int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream,
     p.total_segments = d_total;
     HIP_TRY(hipMemsetAsync(p.next_unit, 0, sizeof(unsigned long long), stream));
     if (d_total) HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), stream));
-    if (use_pinhole(p)) {
+    bool pinhole = use_pinhole(p);
+    if (pinhole) {
+        const double rho = pinhole_rho(p.gen);
+        if (rho < 1e4) p.prim_rho = (float)(rho * (1.0 + 1e-6));
+        else pinhole = false;  // also NaN
+    }
+    if (pinhole) {
         // margin of the shared-origin filter: 64 u * max_j(|p_j - O|^2 + r_j^2), rounded up
         double c2 = 0.0;
         for (const float4& s : scene->host_spheres) {

@@ -156,6 +156,22 @@ struct Slot {
     bool live;        // carries a ray through the next scan
 };
 
+// Generator cell (i, j) of work item m: cell = i * count_v + j (scene_config.rs:74-75).  32-bit division whenever the
+// cell index fits (a 64-bit one costs a few hundred instructions).
+__device__ __forceinline__ void cell_indices(const TraceParams& p, uint32_t m, uint32_t& i, uint32_t& j)
+{
+    const uint64_t cell = p.cell_begin + (uint64_t)m * p.cell_step;
+    const uint32_t cv = p.gen.count_v;
+    if ((cell >> 32) == 0) {
+        const uint32_t c32 = (uint32_t)cell;
+        i = c32 / cv;
+        j = c32 - i * cv;
+    } else {
+        i = (uint32_t)(cell / cv);
+        j = (uint32_t)(cell % cv);
+    }
+}
+
 __device__ __forceinline__ void primary_ray(const TraceParams& p, uint32_t m, F3& o, F3& d, float& ior)
 {
     if (p.rays) {
@@ -166,8 +182,8 @@ __device__ __forceinline__ void primary_ray(const TraceParams& p, uint32_t m, F3
         return;
     }
     const DevGen& g = p.gen;
-    uint64_t cell = p.cell_begin + (uint64_t)m * p.cell_step;
-    uint32_t i = (uint32_t)(cell / g.count_v), j = (uint32_t)(cell % g.count_v);
+    uint32_t i, j;
+    cell_indices(p, m, i, j);
     F3 us = f3(g.u_step[0], g.u_step[1], g.u_step[2]), vs = f3(g.v_step[0], g.v_step[1], g.v_step[2]);
     F3 a = f3(g.a[0], g.a[1], g.a[2]);
     ior = g.current_ior;
@@ -194,13 +210,14 @@ __device__ __forceinline__ F3 sky(F3 d)
 // ---------------------------------------------------------------------------------------------------
 // The scan step: every live slot of the wave against `count` spheres of an LDS tile.
 //   FLAVOR 0  general ray:   pass iff fma(h,h,-S) >= K,  h = p.dh + nod,  S = p.pp + s0        (8 VALU / test)
-//   FLAVOR 1  pinhole ray:   pass iff |p'.dh| >= sK      (tile holds p' = p - O and sK)         (4 VALU / test)
+//   FLAVOR 1  pinhole ray:   pass iff |A' + i B' + j C'| >= L   (tile holds {A, B, C} / sK; L ~ |target - O|)   (3 VALU / test)
 //   FLAVOR 2  exact filter:  pass iff the reference's own discriminant is not < 0 (sphere.rs:13-18)
 // Survivors go to the wave's candidate queue and are confirmed with the exact sequence.
 // ---------------------------------------------------------------------------------------------------
 template <int R>
 struct ScanConsts {
-    F3 dh[R];      // unit direction (NaN for dead slots in FLAVOR 1)
+    F3 dh[R];      // unit direction
+    float ci[R], cj[R], lt[R];  // FLAVOR 1: cell indices i, j and a lower bound of |target - O| (NaN for dead slots)
     float nod[R];  // -(o . dh)
     F3 pp[R];      // -2 o
     float s0[R];   // |o|^2 - margin  (+inf for dead slots)
@@ -220,23 +237,35 @@ __device__ __forceinline__ void scan_step(const float4 (&sp)[kUnroll], unsigned 
     if (FLAVOR == 1) {
         // stage-wise so the kUnroll*R dot products are independent chains (the scan is issue-bound, not latency-bound)
         float h[kUnroll][R];
+        if constexpr (R == 2) {
+            // the two slots of a lane as one packed operand: v_pk_fma_f32 with the table scalars broadcast by op_sel
+            typedef float V2f __attribute__((ext_vector_type(2)));
+            const V2f cj2 = {c.cj[0], c.cj[1]}, ci2 = {c.ci[0], c.ci[1]};
+            V2f hv[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u)
+            for (int u = 0; u < kUnroll; ++u) hv[u] = __builtin_elementwise_fma(cj2, (V2f)(sp[u].z), (V2f)(sp[u].x));
 #pragma unroll
-            for (int r = 0; r < R; ++r) h[u][r] = sp[u].z * c.dh[r].z;
+            for (int u = 0; u < kUnroll; ++u) hv[u] = __builtin_elementwise_fma(ci2, (V2f)(sp[u].y), hv[u]);
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u)
+            for (int u = 0; u < kUnroll; ++u) {
+                h[u][0] = hv[u].x;
+                h[u][1] = hv[u].y;
+            }
+        } else {
 #pragma unroll
-            for (int r = 0; r < R; ++r) h[u][r] = __builtin_fmaf(sp[u].y, c.dh[r].y, h[u][r]);
+            for (int u = 0; u < kUnroll; ++u)
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u)
+                for (int r = 0; r < R; ++r) h[u][r] = __builtin_fmaf(c.cj[r], sp[u].z, sp[u].x);
 #pragma unroll
-            for (int r = 0; r < R; ++r) h[u][r] = __builtin_fmaf(sp[u].x, c.dh[r].x, h[u][r]);
+            for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+                for (int r = 0; r < R; ++r) h[u][r] = __builtin_fmaf(c.ci[r], sp[u].y, h[u][r]);
+        }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                ps[u][r] = __builtin_fabsf(h[u][r]) >= sp[u].w;
+                ps[u][r] = __builtin_fabsf(h[u][r]) >= c.lt[r];
                 mk[u][r] = __ballot(ps[u][r]);
                 any |= mk[u][r];
             }
@@ -276,6 +305,58 @@ __device__ __forceinline__ void scan_step(const float4 (&sp)[kUnroll], unsigned 
     }
 }
 
+// FLAVOR 1 on the packed LDS table: the 12 floats of four spheres arrive as six aligned register pairs, and every table
+// scalar is fed to v_pk_fma_f32 as "low half twice" or "high half twice" of the pair it sits in (op_sel), never copied.
+template <int R>
+__device__ __forceinline__ void scan_step_affine(float __attribute__((ext_vector_type(4))) a, float __attribute__((ext_vector_type(4))) b,
+                                                 float __attribute__((ext_vector_type(4))) d, unsigned jg, const ScanConsts<R>& c,
+                                                 WaveLds<R>& w, const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane)
+{
+    static_assert(R == 2 && kUnroll == 4, "two slots per lane, four spheres per step");
+    typedef float V2f __attribute__((ext_vector_type(2)));
+    const V2f cj2 = {c.cj[0], c.cj[1]}, ci2 = {c.ci[0], c.ci[1]};
+    V2f p0 = a.xy, p1 = a.zw, p2 = b.xy, p3 = b.zw, p4 = d.xy, p5 = d.zw;
+    // opaque to the optimiser from here on: a splat of the 4th element of a 16-byte tuple is not folded into op_sel, a
+    // splat of the 2nd element of a register pair is
+    asm("" : "+v"(p1));
+    asm("" : "+v"(p3));
+    asm("" : "+v"(p5));
+#define RT_LO(p) __builtin_shufflevector(p, p, 0, 0)
+#define RT_HI(p) __builtin_shufflevector(p, p, 1, 1)
+    // sphere 0: A = p0.lo, B = p0.hi, C = p1.lo | 1: p1.hi, p2.lo, p2.hi | 2: p3.lo, p3.hi, p4.lo | 3: p4.hi, p5.lo, p5.hi
+    V2f hv[kUnroll];
+    hv[0] = __builtin_elementwise_fma(cj2, RT_LO(p1), RT_LO(p0));
+    hv[1] = __builtin_elementwise_fma(cj2, RT_HI(p2), RT_HI(p1));
+    hv[2] = __builtin_elementwise_fma(cj2, RT_LO(p4), RT_LO(p3));
+    hv[3] = __builtin_elementwise_fma(cj2, RT_HI(p5), RT_HI(p4));
+    hv[0] = __builtin_elementwise_fma(ci2, RT_HI(p0), hv[0]);
+    hv[1] = __builtin_elementwise_fma(ci2, RT_LO(p2), hv[1]);
+    hv[2] = __builtin_elementwise_fma(ci2, RT_HI(p3), hv[2]);
+    hv[3] = __builtin_elementwise_fma(ci2, RT_LO(p5), hv[3]);
+#undef RT_LO
+#undef RT_HI
+    unsigned long long mk[kUnroll][R];
+    bool ps[kUnroll][R];
+    unsigned long long any = 0;
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+        ps[u][0] = __builtin_fabsf(hv[u].x) >= c.lt[0];
+        ps[u][1] = __builtin_fabsf(hv[u].y) >= c.lt[1];
+        mk[u][0] = __ballot(ps[u][0]);
+        mk[u][1] = __ballot(ps[u][1]);
+        any |= mk[u][0] | mk[u][1];
+    }
+    if (any) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (mk[u][r]) push_candidates<R>(w, sc, mk[u][r], ps[u][r], r * 64, jg + u, head, tail, lane);
+            }
+        }
+    }
+}
+
 // The scan over a whole sphere table.
 //   PF = false: `tile` is the block's LDS table; every step reads kUnroll spheres with wave-uniform ds_read_b128.
 //   PF = true : the table (count % 64 == 0) lives in global memory / L2 (scenes above kTileSpheres).  A wave-uniform
@@ -286,7 +367,20 @@ template <int R, int FLAVOR, bool PF>
 __device__ __forceinline__ void scan_tile(const float4* tile, unsigned count, float4* stage, const ScanConsts<R>& c,
                                           WaveLds<R>& w, const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane)
 {
-    if (!PF) {
+    if (!PF && FLAVOR == 1) {
+        // shared-origin table in LDS: 3 floats per sphere, packed, so kUnroll = 4 spheres are three 16-byte broadcasts
+        // (the table read, not the VALU, is what this loop would otherwise wait for)
+        static_assert(kUnroll == 4, "packed table layout assumes 4 spheres per step");
+        // volatile: the three 16-byte reads are issued as written (otherwise the compiler re-slices them into five narrower ones)
+        typedef float V4f __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const volatile V4f LdsV4;
+        LdsV4* t = (LdsV4*)tile;
+        for (unsigned j = 0; j < count; j += kUnroll) {
+            LdsV4* t3 = t + (j >> 2) * 3u;
+            const V4f a = t3[0], b = t3[1], d = t3[2];
+            scan_step_affine<R>(a, b, d, j, c, w, sc, head, tail, lane);
+        }
+    } else if (!PF) {
         for (unsigned j = 0; j < count; j += kUnroll) {
             float4 sp[kUnroll];
 #pragma unroll

@@ -1,7 +1,9 @@
 // rt_pinhole.hip — the render loop specialised for RayGeneratorConfig::Projector (scene_config.rs:84-108):
-// every primary ray leaves the same origin O, so the primary closest-hit scan (77 % of all segments on the C2
-// workload) needs only  h = (p - O) . d^  and one compare per sphere:  |h| >= sK,  sK = sqrt(|p-O|^2 - r^2 - margin)
-// precomputed per sphere when the block starts.  That is 4 VALU instructions per test instead of 8.
+// every primary ray leaves the same origin O towards target(i, j) = corner + i us + j vs, so the primary closest-hit scan
+// (77 % of all segments on the C2 workload) reduces to an affine form in the cell indices per sphere,
+//   |A' + i B' + j C'| >= |target - O|,   {A, B, C} = (p - O) . {corner - O, us, vs},  ' = divided by sK,
+// with sK = sqrt(|p-O|^2 - r^2 - margin) precomputed per sphere when the block starts.
+// That is 3 VALU instructions per test instead of 8.
 //
 // Rays that hit something leave the primary stream: the scatter result (scene.rs:68-97) is appended to a
 // wave-private ring of continuing rays, and whenever a full wave of them (64*R) has collected, the wave runs
@@ -18,32 +20,48 @@ namespace {
 
 constexpr int kPinThreads = 512;  // 8 waves share the two LDS tables; 2 blocks per CU = 4 waves per SIMD
 
-// One entry of the shared-origin table: {p - O, sK}.
-__device__ __forceinline__ float4 pinhole_entry(const DevScene& sc, unsigned k, F3 O, float prim_margin)
+// One entry of the shared-origin table.  Every primary ray of a Projector points from O to
+// T(i, j) = corner + i us + j vs, so with q = p - O the projection numerator q . (T - O) = A + i B + j C is affine in the
+// cell indices: A = q . (corner - O), B = q . us, C = q . vs.  The entry is {A, B, C} / sK, and the test is
+// |A' + i B' + j C'| >= |T - O|: two FMAs and a compare per ray-sphere pair.
+__device__ __forceinline__ float4 pinhole_entry(const TraceParams& p, unsigned k, F3 O)
 {
-    if (k >= sc.n_sph) return make_float4(0.f, 0.f, 0.f, __builtin_inff());  // padding never passes
+    const DevScene& sc = p.sc;
+    if (k >= sc.n_sph) return make_float4(0.f, 0.f, 0.f, 0.f);  // padding: |0| >= L never passes
     const float4 e = sc.sph_exact[k];
-    // p' = fl(p - O) is exactly minus the reference's local origin fl(O - p) (transform.rs:22), so K' below is
-    // exact for the operands every later test uses.
-    const float px = e.x - O.x, py = e.y - O.y, pz = e.z - O.z;
-    const double K = ((double)px * px + (double)py * py + (double)pz * pz) - (double)e.w * e.w;
-    const double Kq = K - (double)prim_margin;
-    const float sK = (Kq <= 0.0) ? -1.0f : (float)(__builtin_sqrt(Kq) * (1.0 - 0x1p-22));
-    return make_float4(px, py, pz, sK);
+    // q = fl(p - O) is exactly minus the reference's local origin fl(O - p) (transform.rs:22), so K' below is exact for
+    // the operands every later test uses.
+    const float qx = e.x - O.x, qy = e.y - O.y, qz = e.z - O.z;
+    const double qq = (double)qx * qx + (double)qy * qy + (double)qz * qz;
+    const double Kq = (qq - (double)e.w * e.w) - (double)p.prim_margin;
+    const float4 always = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);  // inf + i 0 + j 0 passes against every L
+    if (!(Kq > 0.0)) return always;
+    const double qn = __builtin_sqrt(qq);
+    const double sK = (__builtin_sqrt(Kq) - 0x1p-24 * qn * (4.0 + 2.0 * (double)p.prim_rho)) * (1.0 - 0x1p-22);
+    if (!(sK > 1e-6 * qn)) return always;
+    const DevGen& g = p.gen;
+    const double cx = (double)g.corner[0] - (double)O.x, cy = (double)g.corner[1] - (double)O.y, cz = (double)g.corner[2] - (double)O.z;
+    const double A = qx * cx + qy * cy + qz * cz;
+    const double B = (double)qx * g.u_step[0] + (double)qy * g.u_step[1] + (double)qz * g.u_step[2];
+    const double C = (double)qx * g.v_step[0] + (double)qy * g.v_step[1] + (double)qz * g.v_step[2];
+    const float a = (float)(A / sK), b = (float)(B / sK), c = (float)(C / sK);
+    const float big = 1e30f;
+    if (!(__builtin_fabsf(a) < big && __builtin_fabsf(b) < big && __builtin_fabsf(c) < big)) return always;  // no 0 * inf later
+    return make_float4(a, b, c, 0.f);
 }
 
 // Streamed variant: the table is built once per launch in global memory.
 __global__ void pinhole_table_kernel(const TraceParams p, float4* table)
 {
     const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < p.sc.n_sph_pad) table[k] = pinhole_entry(p.sc, k, f3(p.gen.a[0], p.gen.a[1], p.gen.a[2]), p.prim_margin);
+    if (k < p.sc.n_sph_pad) table[k] = pinhole_entry(p, k, f3(p.gen.a[0], p.gen.a[1], p.gen.a[2]));
 }
 
 // STREAM = false: both tables (<= kTileSpheres spheres) live in LDS.  STREAM = true: both are streamed from global / L2.
 template <int R, bool STREAM, bool CX>
 __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TraceParams p)
 {
-    extern __shared__ float4 tiles[];  // [n_sph_pad] general {p, K}  then  [n_sph_pad] pinhole {p - O, sK}  (LDS mode)
+    extern __shared__ float4 tiles[];  // [n_sph_pad] general {p, K}, then 3 floats per sphere {A, B, C} / sK (LDS mode), then the BVH top
     __shared__ WaveLds<R> wl[kPinThreads / 64];
     __shared__ float4 stage_all[STREAM ? (kPinThreads / 64) * 128 : 1];
 
@@ -60,11 +78,15 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
     if (!STREAM) {
         for (unsigned k = threadIdx.x; k < n_pad; k += kPinThreads) {
             tiles[k] = sc.sph_cull[k];
-            tiles[n_pad + k] = pinhole_entry(sc, k, O, p.prim_margin);
+            const float4 e = pinhole_entry(p, k, O);
+            float* t3 = reinterpret_cast<float*>(tiles + n_pad) + 3u * k;  // packed: 12 bytes per sphere
+            t3[0] = e.x;
+            t3[1] = e.y;
+            t3[2] = e.z;
         }
     }
     // triangle meshes: the top of the BVH (first nodes of the breadth-first array) sits behind the tables
-    float4* bvh_top = tiles + (STREAM ? 0u : 2u * n_pad);
+    float4* bvh_top = tiles + (STREAM ? 0u : n_pad + (n_pad >> 2) * 3u);
     if (CX) {
         const float4* src = reinterpret_cast<const float4*>(sc.bvh_nodes);
         for (unsigned k = threadIdx.x; k < p.bvh_lds_nodes * 8u; k += kPinThreads) bvh_top[k] = src[k];
@@ -152,9 +174,15 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 w.stash[3][slot] = rd[r].x; w.stash[4][slot] = rd[r].y; w.stash[5][slot] = rd[r].z;
                 w.stash[6][slot] = a;
                 w.best[slot] = kNoHit;
-                const float rs = 1.0f / __builtin_sqrtf(a);
-                const float nanv = __builtin_nanf("");
-                c.dh[r] = live[r] ? rd[r] * rs : f3(nanv, nanv, nanv);  // NaN never passes |h| >= sK
+                // shared-origin filter constants: cell indices (exact in f32) and a lower bound of |target - O|
+                uint32_t ci, cj;
+                cell_indices(p, live[r] ? um[r] : 0u, ci, cj);
+                c.ci[r] = (float)ci;
+                c.cj[r] = (float)cj;
+                const F3 corner = f3(p.gen.corner[0], p.gen.corner[1], p.gen.corner[2]);
+                const F3 us = f3(p.gen.u_step[0], p.gen.u_step[1], p.gen.u_step[2]), vs = f3(p.gen.v_step[0], p.gen.v_step[1], p.gen.v_step[2]);
+                const F3 dv = ((corner + (c.ci[r] * us)) + (c.cj[r] * vs)) - O;  // the reference's target - origin (scene_config.rs:98-100)
+                c.lt[r] = live[r] ? __builtin_sqrtf(dot(dv, dv)) * (1.0f - 0x1p-20f) : __builtin_nanf("");  // NaN: dead slots never pass
             }
             wave_lds_sync();
             scan_tile<R, 1, STREAM>(tileP, n_pad, stage, c, w, sc, head, tail, lane);
@@ -303,7 +331,7 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
 constexpr int kR = 2;
 
 inline bool stream_mode(const TraceParams& p) { return p.sc.n_sph_pad > (uint32_t)kTileSpheres; }
-inline size_t table_lds(const TraceParams& p) { return stream_mode(p) ? 0 : (size_t)p.sc.n_sph_pad * sizeof(float4) * 2; }
+inline size_t table_lds(const TraceParams& p) { return stream_mode(p) ? 0 : (size_t)p.sc.n_sph_pad * (sizeof(float4) + 3 * sizeof(float)); }
 constexpr size_t kLdsPerBlock = 80 * 1024;  // two 512-thread blocks per CU share 160 KB
 inline size_t dyn_lds(const TraceParams& p) { return table_lds(p) + (size_t)p.bvh_lds_nodes * sizeof(BvhNode); }
 

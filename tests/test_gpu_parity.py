@@ -573,3 +573,43 @@ def _render_rank(sc, cfg, st, rank, world, dev):
         return sharding.render_sharded(sc, cfg["gen"], 5, st, 3, rank, world, NoGather(), dev, max_cells_per_launch=200)
     finally:
         sharding.gather_image = orig
+
+
+@pytest.mark.parametrize("case", ["centered", "offset", "skewed"])
+def test_projector_rays_grazing_sphere_limbs(engine, case):
+    """Stress for the shared-origin (affine) filter of the Projector kernel: every sphere is placed so that the ray of one
+    particular cell passes within +-1e-5 r (some within +-1e-7 r) of its limb, at assorted distances, for projectors near
+    the origin, far from it (large coordinates: more rounding in the target) and with a skewed target parallelogram.
+    First-hit ids, t and the image must still equal the oracle's, i.e. the filter never dropped a pair the exact test accepts."""
+    rng = np.random.default_rng({"centered": 1, "offset": 2, "skewed": 3}[case])
+    cu, cv = 96, 64
+    if case == "centered":
+        O, corner, u, v = (0.0, 0.0, -120.0), (-64.0, -36.0, -60.0), (128.0, 0.0, 0.0), (0.0, 72.0, 0.0)
+    elif case == "offset":
+        O, corner, u, v = (900.0, -400.0, 2000.0), (880.0, -415.0, 2030.0), (40.0, 0.0, 3.0), (0.0, 30.0, 1.0)
+    else:
+        O, corner, u, v = (5.0, 3.0, -40.0), (-30.0, -20.0, 10.0), (50.0, 10.0, 25.0), (-8.0, 45.0, 5.0)
+    gen = projector(O, corner, u, v, cu, cv)
+    f32 = np.float32
+    O32, c32 = np.array(O, f32), np.array(corner, f32)
+    us, vs = (np.array(u, f32) / f32(cu)).astype(f32), (np.array(v, f32) / f32(cv)).astype(f32)
+    n = 700
+    ci, cj = rng.integers(0, cu, n), rng.integers(0, cv, n)
+    target = ((c32 + ci[:, None].astype(f32) * us).astype(f32) + cj[:, None].astype(f32) * vs).astype(f32)
+    d = (target - O32).astype(np.float64)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rad = rng.uniform(0.3, 3.0, n)
+    dist = rng.uniform(1.2, 6.0, n) * np.linalg.norm(np.array(u)) + 5.0 * rad
+    perp = np.cross(d, rng.normal(size=(n, 3)))
+    perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    eps = np.where(rng.random(n) < 0.3, 1e-7, 1e-5) * rng.uniform(-1, 1, n)
+    centre = np.array(O) + d * dist[:, None] + perp * (rad * (1.0 + eps))[:, None]
+    kinds = [abi.RT_MAT_GLASS, abi.RT_MAT_MIRROR, abi.RT_MAT_HALF_MIRROR]
+    objs = np.array([sphere(centre[k], rad[k], kinds[k % 3], [1.5, 0.0, 0.5][k % 3]) for k in range(n)], dtype=abi.OBJECT_DTYPE)
+    st = SimulationSettingsConfig(80.0, 4)
+    got = engine.Scene(objs).render(gen, 2, st, seed=6)
+    want = ob.OracleScene(objs).render(gen, 2, 80.0, 4, seed=6, threads=8)
+    for a, b in zip(got[:4], want[:4]):
+        assert same(a, b)
+    assert got[4] == want[4]
+    assert (got[1] >= 0).mean() > 0.05  # the spheres are where the rays go

@@ -12,12 +12,13 @@ h = int(sys.argv[2]) if len(sys.argv) > 2 else 1080
 spp = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 cfgname = sys.argv[5] if len(sys.argv) > 5 else "c2"
+depth = int(sys.argv[6]) if len(sys.argv) > 6 else None
 engine.init(0)
 cfg = {"c2": synth.config_c2, "c3": synth.config_c3, "c4": synth.config_c4}[cfgname](w, h)
 t0 = __import__("time").perf_counter()
 sc = engine.Scene(cfg["objects"], meshes=cfg.get("meshes"))
 print(f"scene build {(__import__('time').perf_counter() - t0)*1e3:.1f} ms", flush=True)
-st = SimulationSettingsConfig(cfg["infinity_distance"], cfg["max_bounces"])
+st = SimulationSettingsConfig(cfg["infinity_distance"], depth or cfg["max_bounces"])
 import time
 for r in range(reps):
     t0 = time.perf_counter()
