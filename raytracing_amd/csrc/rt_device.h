@@ -234,42 +234,8 @@ __device__ __forceinline__ void scan_step(const float4 (&sp)[kUnroll], unsigned 
     unsigned long long mk[kUnroll][R];
     bool ps[kUnroll][R];
     unsigned long long any = 0;
-    if (FLAVOR == 1) {
-        // stage-wise so the kUnroll*R dot products are independent chains (the scan is issue-bound, not latency-bound)
-        float h[kUnroll][R];
-        if constexpr (R == 2) {
-            // the two slots of a lane as one packed operand: v_pk_fma_f32 with the table scalars broadcast by op_sel
-            typedef float V2f __attribute__((ext_vector_type(2)));
-            const V2f cj2 = {c.cj[0], c.cj[1]}, ci2 = {c.ci[0], c.ci[1]};
-            V2f hv[kUnroll];
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) hv[u] = __builtin_elementwise_fma(cj2, (V2f)(sp[u].z), (V2f)(sp[u].x));
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) hv[u] = __builtin_elementwise_fma(ci2, (V2f)(sp[u].y), hv[u]);
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                h[u][0] = hv[u].x;
-                h[u][1] = hv[u].y;
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
-#pragma unroll
-                for (int r = 0; r < R; ++r) h[u][r] = __builtin_fmaf(c.cj[r], sp[u].z, sp[u].x);
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
-#pragma unroll
-                for (int r = 0; r < R; ++r) h[u][r] = __builtin_fmaf(c.ci[r], sp[u].y, h[u][r]);
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u)
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                ps[u][r] = __builtin_fabsf(h[u][r]) >= c.lt[r];
-                mk[u][r] = __ballot(ps[u][r]);
-                any |= mk[u][r];
-            }
-    } else {
+    static_assert(FLAVOR != 1, "the shared-origin filter runs in scan_step_affine");
+    {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
 #pragma unroll
@@ -367,7 +333,7 @@ template <int R, int FLAVOR, bool PF>
 __device__ __forceinline__ void scan_tile(const float4* tile, unsigned count, float4* stage, const ScanConsts<R>& c,
                                           WaveLds<R>& w, const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane)
 {
-    if (!PF && FLAVOR == 1) {
+    if constexpr (!PF && FLAVOR == 1) {
         // shared-origin table in LDS: 3 floats per sphere, packed, so kUnroll = 4 spheres are three 16-byte broadcasts
         // (the table read, not the VALU, is what this loop would otherwise wait for)
         static_assert(kUnroll == 4, "packed table layout assumes 4 spheres per step");
@@ -380,12 +346,42 @@ __device__ __forceinline__ void scan_tile(const float4* tile, unsigned count, fl
             const V4f a = t3[0], b = t3[1], d = t3[2];
             scan_step_affine<R>(a, b, d, j, c, w, sc, head, tail, lane);
         }
-    } else if (!PF) {
+    } else if constexpr (!PF) {
         for (unsigned j = 0; j < count; j += kUnroll) {
             float4 sp[kUnroll];
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) sp[u] = tile[j + u];
             scan_step<R, FLAVOR>(sp, j, c, w, sc, head, tail, lane);
+        }
+    } else if constexpr (FLAVOR == 1) {
+        // streamed shared-origin table: packed 12-byte entries in global memory, one per lane per load, parked in the
+        // wave's staging buffer in the same packed form and then read exactly like the LDS-resident table
+        if (count == 0) return;
+        typedef float V4f __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const volatile V4f LdsV4;
+        const float* g = reinterpret_cast<const float*>(tile);
+        float* st = reinterpret_cast<float*>(stage);
+        float n0 = g[3u * lane], n1 = g[3u * lane + 1], n2 = g[3u * lane + 2];
+        unsigned buf = 0;
+        for (unsigned base = 0; base < count; base += 64) {
+            float* sb = st + buf * 192u;
+            sb[3u * lane] = n0;
+            sb[3u * lane + 1] = n1;
+            sb[3u * lane + 2] = n2;
+            if (base + 64 < count) {
+                const float* gn = g + 3u * (base + 64 + lane);
+                n0 = gn[0];
+                n1 = gn[1];
+                n2 = gn[2];
+            }
+            wave_lds_sync();
+            LdsV4* t = (LdsV4*)sb;
+            for (unsigned j = 0; j < 64; j += kUnroll) {
+                LdsV4* t3 = t + (j >> 2) * 3u;
+                const V4f a = t3[0], b = t3[1], d = t3[2];
+                scan_step_affine<R>(a, b, d, base + j, c, w, sc, head, tail, lane);
+            }
+            buf ^= 1;
         }
     } else {
         if (count == 0) return;

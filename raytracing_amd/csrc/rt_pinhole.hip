@@ -54,7 +54,13 @@ __device__ __forceinline__ float4 pinhole_entry(const TraceParams& p, unsigned k
 __global__ void pinhole_table_kernel(const TraceParams p, float4* table)
 {
     const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < p.sc.n_sph_pad) table[k] = pinhole_entry(p, k, f3(p.gen.a[0], p.gen.a[1], p.gen.a[2]));
+    if (k < p.sc.n_sph_pad) {
+        const float4 e = pinhole_entry(p, k, f3(p.gen.a[0], p.gen.a[1], p.gen.a[2]));
+        float* t3 = reinterpret_cast<float*>(table) + 3u * k;  // packed: 12 bytes per sphere
+        t3[0] = e.x;
+        t3[1] = e.y;
+        t3[2] = e.z;
+    }
 }
 
 // STREAM = false: both tables (<= kTileSpheres spheres) live in LDS.  STREAM = true: both are streamed from global / L2.
