@@ -613,3 +613,18 @@ def test_projector_rays_grazing_sphere_limbs(engine, case):
         assert same(a, b)
     assert got[4] == want[4]
     assert (got[1] >= 0).mean() > 0.05  # the spheres are where the rays go
+
+
+def test_projector_with_origin_in_the_target_plane_uses_the_general_kernel(engine):
+    """rho = inf: the shared-origin filter has no rounding budget, the launch must take the general kernel
+    and still equal the oracle.  Also a projector whose plane is merely very close to its origin (large rho, loose filter)."""
+    objs = random_scene(120, 1, seed=33, extent=(10.0, 10.0, 10.0), r_min=0.3, r_max=1.0)
+    st = SimulationSettingsConfig(30.0, 5)
+    sc, osc = engine.Scene(objs), ob.OracleScene(objs)
+    for O, corner in [((0.0, 0.0, 0.0), (-6.0, -6.0, 0.0)), ((0.0, 0.0, -0.004), (-6.0, -6.0, 0.0)), ((0.0, 0.0, -0.5), (-6.0, -6.0, 0.0))]:
+        gen = projector(O, corner, (12.0, 0.0, 0.0), (0.0, 12.0, 0.0), 40, 30)
+        got = sc.render(gen, 2, st, seed=2)
+        want = osc.render(gen, 2, 30.0, 5, seed=2, threads=4)
+        for a, b in zip(got[:4], want[:4]):
+            assert same(a, b)
+        assert got[4] == want[4]
