@@ -105,7 +105,7 @@ struct TraceParams {
     uint32_t* secq;     // per-wave rings of continuing rays: [grid waves][kSecFields][kSecCap] dwords
     float prim_margin;  // >= 64 u * max_j(|p_j - O|^2 + r_j^2): margin of the shared-origin filter
     float prim_rho;     // (3G + 7M) / d_min of the Projector: rounding of the affine numerator relative to |target - O|
-    float4* prim_table; // streamed mode only: [n_sph_pad] {p - O, sK}, rebuilt per launch
+    float4* prim_table; // streamed mode only: 3 floats per sphere {A, B, C} / sK (packed), rebuilt per launch
     uint32_t bvh_lds_nodes;  // pinhole kernel: the first this-many BvhNodes are copied into LDS (set by launch_pinhole)
 };
 

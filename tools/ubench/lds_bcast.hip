@@ -46,6 +46,51 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* stamps)
     if (q.x + q.y + acc.x + acc.w == 12345.678f) out[0] = q.x;
 }
 
+// v_pk_fma_f32 with the broadcast operand in an SGPR pair instead of a VGPR pair (would a scalar-loaded table be as fast?)
+template <int SGPR>
+__global__ __launch_bounds__(512) void kp(float* out, unsigned long long* stamps, float sa, float sb)
+{
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    V2f x0 = {1.f, 2.f}, x1 = x0, x2 = x0, x3 = x0, x4 = x0, x5 = x0, x6 = x0, x7 = x0, a = {0.001f, 0.001f};
+    V2f mv = {sa + threadIdx.x * 1e-9f, sb};
+    V2f ms = {sa, sb};
+    for (int i = 0; i < ITERS; ++i) {
+        if (SGPR)
+            asm volatile("v_pk_fma_f32 %0, %0, %8, %9 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %1, %1, %8, %9 op_sel:[0,1,0]\n v_pk_fma_f32 %2, %2, %8, %9 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %3, %3, %8, %9 op_sel:[0,1,0]\n"
+                         "v_pk_fma_f32 %4, %4, %8, %9 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %5, %5, %8, %9 op_sel:[0,1,0]\n v_pk_fma_f32 %6, %6, %8, %9 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %7, %7, %8, %9 op_sel:[0,1,0]\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(ms), "v"(a));
+        else
+            asm volatile("v_pk_fma_f32 %0, %0, %8, %9 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %1, %1, %8, %9 op_sel:[0,1,0]\n v_pk_fma_f32 %2, %2, %8, %9 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %3, %3, %8, %9 op_sel:[0,1,0]\n"
+                         "v_pk_fma_f32 %4, %4, %8, %9 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %5, %5, %8, %9 op_sel:[0,1,0]\n v_pk_fma_f32 %6, %6, %8, %9 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %7, %7, %8, %9 op_sel:[0,1,0]\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(mv), "v"(a));
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stamps[0] = t1 - t0; stamps[1] = r1 - r0; }
+    V2f q = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+    if (q.x + q.y == 12345.678f) out[0] = q.x;
+}
+
+template <int SGPR>
+void runp(const char* name, int n_cu, float* dout, unsigned long long* dst)
+{
+    const int blocks = n_cu * 2;
+    kp<SGPR><<<blocks, 512>>>(dout, dst, 0.999f, 0.998f);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 3; ++r) kp<SGPR><<<blocks, 512>>>(dout, dst, 0.999f, 0.998f);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long st[2];
+    CK(hipMemcpy(st, dst, 16, hipMemcpyDeviceToHost));
+    const double ghz = (double)st[0] / (double)st[1] * 0.1, s = ms * 1e-3 / 3;
+    printf("%-44s %7.3f ms  clk %.2f GHz  %6.2f cycles per wave instruction per SIMD\n", name, ms / 3, ghz, s * ghz * 1e9 / (4.0 * ITERS * 8));
+}
+
 template <int READS, int FMAS, int WIDTH>
 void run(const char* name, int n_cu, float* dout, unsigned long long* dst)
 {
@@ -87,5 +132,7 @@ int main()
     run<3, 8, 128>("3 x b128 + 8 v_pk_fma", n_cu, dout, dst);
     run<3, 16, 128>("3 x b128 + 16 v_pk_fma", n_cu, dout, dst);
     run<2, 16, 128>("2 x b128 + 16 v_pk_fma", n_cu, dout, dst);
+    runp<0>("v_pk_fma_f32, broadcast operand in VGPRs", n_cu, dout, dst);
+    runp<1>("v_pk_fma_f32, broadcast operand in SGPRs", n_cu, dout, dst);
     return 0;
 }
