@@ -1,4 +1,6 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -628,3 +630,15 @@ def test_projector_with_origin_in_the_target_plane_uses_the_general_kernel(engin
         for a, b in zip(got[:4], want[:4]):
             assert same(a, b)
         assert got[4] == want[4]
+
+
+def test_projector_filter_differential_fuzz():
+    """tools/fuzz_pinhole.py: 300 random projector / sphere-cloud configurations rendered with the shared-origin filter and
+    with the reference's own discriminant as the filter (scan mode 1, general kernel) must be bit-identical."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_pinhole.py"), "300", "7000"], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "300 cases, 0 mismatches" in r.stdout
