@@ -301,24 +301,19 @@ __device__ __forceinline__ void scan_step_affine(float __attribute__((ext_vector
     hv[3] = __builtin_elementwise_fma(ci2, RT_LO(p5), hv[3]);
 #undef RT_LO
 #undef RT_HI
-    unsigned long long mk[kUnroll][R];
-    bool ps[kUnroll][R];
-    unsigned long long any = 0;
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-        ps[u][0] = __builtin_fabsf(hv[u].x) >= c.lt[0];
-        ps[u][1] = __builtin_fabsf(hv[u].y) >= c.lt[1];
-        mk[u][0] = __ballot(ps[u][0]);
-        mk[u][1] = __ballot(ps[u][1]);
-        any |= mk[u][0] | mk[u][1];
-    }
-    if (any) {
+    // fast path: the threshold is per ray, not per sphere, so "does any of the four pass" is one v_max3 and two compares per
+    // slot instead of four compares; the individual masks are only built when something did pass (about one step in ten)
+    const float m0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(hv[0].x), __builtin_fabsf(hv[1].x)), __builtin_fabsf(hv[2].x));
+    const float m1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(hv[0].y), __builtin_fabsf(hv[1].y)), __builtin_fabsf(hv[2].y));
+    const bool any0 = (m0 >= c.lt[0]) | (__builtin_fabsf(hv[3].x) >= c.lt[0]);
+    const bool any1 = (m1 >= c.lt[1]) | (__builtin_fabsf(hv[3].y) >= c.lt[1]);
+    if (__ballot(any0 | any1)) {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (mk[u][r]) push_candidates<R>(w, sc, mk[u][r], ps[u][r], r * 64, jg + u, head, tail, lane);
-            }
+            const bool p0 = __builtin_fabsf(hv[u].x) >= c.lt[0], p1 = __builtin_fabsf(hv[u].y) >= c.lt[1];
+            const unsigned long long k0 = __ballot(p0), k1 = __ballot(p1);
+            if (k0) push_candidates<R>(w, sc, k0, p0, 0, jg + u, head, tail, lane);
+            if (k1) push_candidates<R>(w, sc, k1, p1, 64, jg + u, head, tail, lane);
         }
     }
 }
