@@ -271,17 +271,18 @@ __device__ __forceinline__ void scan_step(const float4 (&sp)[kUnroll], unsigned 
     }
 }
 
-// FLAVOR 1 on the packed LDS table: the 12 floats of four spheres arrive as six aligned register pairs, and every table
+// FLAVOR 1 on the packed table: the 12 floats of four spheres arrive as six aligned register pairs, and every table
 // scalar is fed to v_pk_fma_f32 as "low half twice" or "high half twice" of the pair it sits in (op_sel), never copied.
+typedef float RtV2f __attribute__((ext_vector_type(2)));
+typedef float RtV4f __attribute__((ext_vector_type(4)));
+
+// hv[u] = {A + i B + j C of sphere u for slot 0, for slot 1}: eight v_pk_fma_f32 for four spheres x two rays.
 template <int R>
-__device__ __forceinline__ void scan_step_affine(float __attribute__((ext_vector_type(4))) a, float __attribute__((ext_vector_type(4))) b,
-                                                 float __attribute__((ext_vector_type(4))) d, unsigned jg, const ScanConsts<R>& c,
-                                                 WaveLds<R>& w, const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane)
+__device__ __forceinline__ void affine_h4(RtV4f a, RtV4f b, RtV4f d, const ScanConsts<R>& c, RtV2f (&hv)[4])
 {
     static_assert(R == 2 && kUnroll == 4, "two slots per lane, four spheres per step");
-    typedef float V2f __attribute__((ext_vector_type(2)));
-    const V2f cj2 = {c.cj[0], c.cj[1]}, ci2 = {c.ci[0], c.ci[1]};
-    V2f p0 = a.xy, p1 = a.zw, p2 = b.xy, p3 = b.zw, p4 = d.xy, p5 = d.zw;
+    const RtV2f cj2 = {c.cj[0], c.cj[1]}, ci2 = {c.ci[0], c.ci[1]};
+    RtV2f p0 = a.xy, p1 = a.zw, p2 = b.xy, p3 = b.zw, p4 = d.xy, p5 = d.zw;
     // opaque to the optimiser from here on: a splat of the 4th element of a 16-byte tuple is not folded into op_sel, a
     // splat of the 2nd element of a register pair is
     asm("" : "+v"(p1));
@@ -290,7 +291,6 @@ __device__ __forceinline__ void scan_step_affine(float __attribute__((ext_vector
 #define RT_LO(p) __builtin_shufflevector(p, p, 0, 0)
 #define RT_HI(p) __builtin_shufflevector(p, p, 1, 1)
     // sphere 0: A = p0.lo, B = p0.hi, C = p1.lo | 1: p1.hi, p2.lo, p2.hi | 2: p3.lo, p3.hi, p4.lo | 3: p4.hi, p5.lo, p5.hi
-    V2f hv[kUnroll];
     hv[0] = __builtin_elementwise_fma(cj2, RT_LO(p1), RT_LO(p0));
     hv[1] = __builtin_elementwise_fma(cj2, RT_HI(p2), RT_HI(p1));
     hv[2] = __builtin_elementwise_fma(cj2, RT_LO(p4), RT_LO(p3));
@@ -301,20 +301,60 @@ __device__ __forceinline__ void scan_step_affine(float __attribute__((ext_vector
     hv[3] = __builtin_elementwise_fma(ci2, RT_LO(p5), hv[3]);
 #undef RT_LO
 #undef RT_HI
-    // fast path: the threshold is per ray, not per sphere, so "does any of the four pass" is one v_max3 and two compares per
-    // slot instead of four compares; the individual masks are only built when something did pass (about one step in ten)
-    const float m0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(hv[0].x), __builtin_fabsf(hv[1].x)), __builtin_fabsf(hv[2].x));
-    const float m1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(hv[0].y), __builtin_fabsf(hv[1].y)), __builtin_fabsf(hv[2].y));
+}
+
+// slow path of the shared-origin scan: individual masks of four spheres, survivors to the candidate ring
+template <int R>
+__device__ __forceinline__ void affine_push4(const RtV2f (&hv)[4], unsigned jg, const ScanConsts<R>& c, WaveLds<R>& w, const DevScene& sc,
+                                             unsigned& head, unsigned& tail, unsigned lane)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool p0 = __builtin_fabsf(hv[u].x) >= c.lt[0], p1 = __builtin_fabsf(hv[u].y) >= c.lt[1];
+        const unsigned long long k0 = __ballot(p0), k1 = __ballot(p1);
+        if (k0) push_candidates<R>(w, sc, k0, p0, 0, jg + u, head, tail, lane);
+        if (k1) push_candidates<R>(w, sc, k1, p1, 64, jg + u, head, tail, lane);
+    }
+}
+
+__device__ __forceinline__ float max3_abs(float a, float b, float c)
+{
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c));
+}
+
+// The threshold is per ray, not per sphere, so "does any sphere of the group pass" is a v_max3 chain and two compares per
+// slot instead of one compare per sphere; the individual masks are only built when something did pass.
+template <int R>
+__device__ __forceinline__ void scan_step_affine(RtV4f a, RtV4f b, RtV4f d, unsigned jg, const ScanConsts<R>& c, WaveLds<R>& w,
+                                                 const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane)
+{
+    RtV2f hv[4];
+    affine_h4<R>(a, b, d, c, hv);
+    const float m0 = max3_abs(hv[0].x, hv[1].x, hv[2].x), m1 = max3_abs(hv[0].y, hv[1].y, hv[2].y);
     const bool any0 = (m0 >= c.lt[0]) | (__builtin_fabsf(hv[3].x) >= c.lt[0]);
     const bool any1 = (m1 >= c.lt[1]) | (__builtin_fabsf(hv[3].y) >= c.lt[1]);
+    if (__ballot(any0 | any1)) affine_push4<R>(hv, jg, c, w, sc, head, tail, lane);
+}
+
+// Eight spheres per decision: three v_max3 and two compares per slot.
+template <int R>
+__device__ __forceinline__ void scan_step_affine8(RtV4f a0, RtV4f b0, RtV4f d0, RtV4f a1, RtV4f b1, RtV4f d1, unsigned jg,
+                                                  const ScanConsts<R>& c, WaveLds<R>& w, const DevScene& sc, unsigned& head,
+                                                  unsigned& tail, unsigned lane)
+{
+    RtV2f hA[4], hB[4];
+    affine_h4<R>(a0, b0, d0, c, hA);
+    affine_h4<R>(a1, b1, d1, c, hB);
+    float m0 = max3_abs(hA[0].x, hA[1].x, hA[2].x), m1 = max3_abs(hA[0].y, hA[1].y, hA[2].y);
+    m0 = max3_abs(m0, hA[3].x, hB[0].x);
+    m1 = max3_abs(m1, hA[3].y, hB[0].y);
+    m0 = max3_abs(m0, hB[1].x, hB[2].x);
+    m1 = max3_abs(m1, hB[1].y, hB[2].y);
+    const bool any0 = (m0 >= c.lt[0]) | (__builtin_fabsf(hB[3].x) >= c.lt[0]);
+    const bool any1 = (m1 >= c.lt[1]) | (__builtin_fabsf(hB[3].y) >= c.lt[1]);
     if (__ballot(any0 | any1)) {
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const bool p0 = __builtin_fabsf(hv[u].x) >= c.lt[0], p1 = __builtin_fabsf(hv[u].y) >= c.lt[1];
-            const unsigned long long k0 = __ballot(p0), k1 = __ballot(p1);
-            if (k0) push_candidates<R>(w, sc, k0, p0, 0, jg + u, head, tail, lane);
-            if (k1) push_candidates<R>(w, sc, k1, p1, 64, jg + u, head, tail, lane);
-        }
+        affine_push4<R>(hA, jg, c, w, sc, head, tail, lane);
+        affine_push4<R>(hB, jg + 4, c, w, sc, head, tail, lane);
     }
 }
 
@@ -336,7 +376,13 @@ __device__ __forceinline__ void scan_tile(const float4* tile, unsigned count, fl
         typedef float V4f __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(3))) const volatile V4f LdsV4;
         LdsV4* t = (LdsV4*)tile;
-        for (unsigned j = 0; j < count; j += kUnroll) {
+        unsigned j = 0;
+        for (; j + 2 * kUnroll <= count; j += 2 * kUnroll) {
+            LdsV4* t6 = t + (j >> 2) * 3u;
+            const V4f a0 = t6[0], b0 = t6[1], d0 = t6[2], a1 = t6[3], b1 = t6[4], d1 = t6[5];
+            scan_step_affine8<R>(a0, b0, d0, a1, b1, d1, j, c, w, sc, head, tail, lane);
+        }
+        if (j < count) {  // count is a multiple of four
             LdsV4* t3 = t + (j >> 2) * 3u;
             const V4f a = t3[0], b = t3[1], d = t3[2];
             scan_step_affine<R>(a, b, d, j, c, w, sc, head, tail, lane);
@@ -371,10 +417,10 @@ __device__ __forceinline__ void scan_tile(const float4* tile, unsigned count, fl
             }
             wave_lds_sync();
             LdsV4* t = (LdsV4*)sb;
-            for (unsigned j = 0; j < 64; j += kUnroll) {
-                LdsV4* t3 = t + (j >> 2) * 3u;
-                const V4f a = t3[0], b = t3[1], d = t3[2];
-                scan_step_affine<R>(a, b, d, base + j, c, w, sc, head, tail, lane);
+            for (unsigned j = 0; j < 64; j += 2 * kUnroll) {
+                LdsV4* t6 = t + (j >> 2) * 3u;
+                const V4f a0 = t6[0], b0 = t6[1], d0 = t6[2], a1 = t6[3], b1 = t6[4], d1 = t6[5];
+                scan_step_affine8<R>(a0, b0, d0, a1, b1, d1, base + j, c, w, sc, head, tail, lane);
             }
             buf ^= 1;
         }
