@@ -150,9 +150,11 @@ def main():
         torch.cuda.synchronize()
 
     # bring the GPU to its steady clocks before anything is counted (a cold first frame runs ~8 % slower); untimed, like the W warmup steps
+    # (render only, no collective: the number of pre-warm frames is time-based and may differ between ranks)
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < 0.5:
-        step()
+        scene.render_dev(cfg["gen"], cfg["spp"], st, seed, 0, n_cells, 1, fbs[0].data_ptr(), first_id.data_ptr(), first_t.data_ptr(),
+                         seg.data_ptr(), total.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
