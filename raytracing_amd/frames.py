@@ -45,9 +45,9 @@ def render_frames(frames_dir, out_dir, spp, seed=0, generator=0, rank=0, world=1
     files = frame_files(frames_dir)
     mine = frames_of_rank(len(files), rank, world)
     done = []
-    with ThreadPoolExecutor(max_workers=2) as pool:
+    with ThreadPoolExecutor(max_workers=4) as pool:
         nxt = pool.submit(_load, os.path.join(frames_dir, files[mine[0]]), generator) if mine else None
-        writing = None
+        writing = []  # up to 3 images being reordered / written while the GPU renders on
         for k, f in enumerate(mine):
             settings, objs, nodes, gen = nxt.result()
             if k + 1 < len(mine):
@@ -55,13 +55,13 @@ def render_frames(frames_dir, out_dir, spp, seed=0, generator=0, rank=0, world=1
             scene = engine.Scene(objs, nodes=nodes)
             fb, _, _, _, total = scene.render(gen, spp, settings, seed=seed)
             del scene
-            if writing is not None:
-                writing.result()
+            while len(writing) >= 3:
+                writing.pop(0).result()
             path = os.path.join(out_dir, f"frame_{f:05d}.pfm")
-            writing = pool.submit(writer, path, fb, gen.count_u, gen.count_v)
+            writing.append(pool.submit(writer, path, fb, gen.count_u, gen.count_v))
             done.append((f, path, int(total)))
-        if writing is not None:
-            writing.result()
+        for wr in writing:
+            wr.result()
     return done
 
 

@@ -18,6 +18,7 @@
 #include <cinttypes>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <dirent.h>
 #include <fstream>
 #include <future>
@@ -138,7 +139,15 @@ int run_frames(const std::string& frames_dir, const std::string& out_dir, size_t
     std::sort(files.begin(), files.end());
     // the host side of frame f+world (TOML parse, flatten) and the image write of frame f-world overlap the GPU work of f
     std::future<Frame> next;
-    std::future<bool> writing;
+    std::deque<std::future<bool>> writing;  // up to kWriters images being reordered / written while the GPU renders on
+    constexpr size_t kWriters = 3;
+    auto drain = [&](size_t keep) {
+        while (writing.size() > keep) {
+            if (!writing.front().get()) return false;
+            writing.pop_front();
+        }
+        return true;
+    };
     size_t f = (size_t)rank;
     if (f < files.size()) next = std::async(std::launch::async, load_frame, frames_dir + "/" + files[f]);
     uint64_t total = 0;
@@ -155,16 +164,16 @@ int run_frames(const std::string& frames_dir, const std::string& out_dir, size_t
         uint64_t segs = 0;
         if (int rc = render_frame(fr.cfg, gen_index, spp, seed, fb, cu, cv, segs)) return rc;
         total += segs;
-        if (writing.valid() && !writing.get()) {
+        if (!drain(kWriters - 1)) {
             std::fprintf(stderr, "Error: cannot write an image into %s\n", out_dir.c_str());
             return 1;
         }
         char name[64];
         std::snprintf(name, sizeof name, "/frame_%05zu.pfm", f);
-        writing = std::async(std::launch::async, [path = out_dir + name, fb = std::move(fb), cu, cv] { return write_pfm(path, fb, cu, cv); });
+        writing.push_back(std::async(std::launch::async, [path = out_dir + name, fb = std::move(fb), cu, cv] { return write_pfm(path, fb, cu, cv); }));
         ++done;
     }
-    if (writing.valid() && !writing.get()) {
+    if (!drain(0)) {
         std::fprintf(stderr, "Error: cannot write an image into %s\n", out_dir.c_str());
         return 1;
     }
