@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of two library builds on the C2 frame: depth 1 (primary segments only) and depth 8, kernel times from rocprofv3.
+# "old" = a build of another revision copied to raytracing_amd/librt_hip_old.so (selected through RT_HIP_LIBRARY), "new" = the tree's.
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
