@@ -169,7 +169,10 @@ int rt_hip_simulate(const rt_scene* scene, const RtRay* rays, uint64_t n_rays, R
                     uint64_t seed, uint64_t ray_id_base, float* out_points, uint32_t* out_n_points,
                     RtBounceRecord* out_records);
 
-/* Same, device buffers, asynchronous on `stream` (a hipStream_t). */
+/* Same, device buffers, asynchronous on `stream` (a hipStream_t).  The library's scratch buffers are shared by all calls
+ * on the context: calls are serialised on the host by a mutex, and a _dev call enqueued on a different stream than the
+ * previous one first makes its stream wait (hipStreamWaitEvent) for the previous call's work, so _dev calls never overlap
+ * on the device.  Any host thread may call (each entry point selects the init device itself). */
 int rt_hip_simulate_dev(const rt_scene* scene, const RtRay* d_rays, uint64_t n_rays, RtSettings settings,
                         uint64_t seed, uint64_t ray_id_base, float* d_points, uint32_t* d_n_points,
                         RtBounceRecord* d_records, uint64_t* d_total_segments, void* stream);

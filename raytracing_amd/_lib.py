@@ -35,6 +35,29 @@ class RtHipError(RuntimeError):
         self.code = code
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7) and load it by
+    the unversioned name, so if librt_hip.so has already pulled in /opt/rocm's copy, a later `import torch` loads a SECOND
+    runtime, which then finds no GPU ("No HIP GPUs are available").  When torch is installed its copy is therefore loaded first
+    (without importing torch); librt_hip.so's NEEDED libamdhip64.so.7 then resolves to it, and torch finds it already loaded."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return  # torch's runtime is already the process's runtime
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """dlopen librt_hip.so and declare prototypes. Does not touch the GPU."""
     global _LIB
@@ -43,6 +66,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C raytracing_amd/csrc` "
                            "(or __graft_entry__.build()); there is no CPU fallback")
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
     L.rt_hip_init.argtypes = [C.c_int]

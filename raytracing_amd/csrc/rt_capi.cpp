@@ -32,6 +32,11 @@ struct Context {
     size_t secq_bytes = 0;
     float4* prim_table = nullptr;  // streamed shared-origin table (grow-only)
     size_t prim_table_bytes = 0;
+    // The scratch above is shared by every call on the context.  Calls are serialised on the host by g_mu; on the device a
+    // call enqueued on another stream than its predecessor first waits for `last_done` (recorded behind every enqueue).
+    hipEvent_t last_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool last_valid = false;
 };
 Context g_ctx;
 constexpr unsigned kCounterRing = 1024;
@@ -112,11 +117,54 @@ rt::DevGen make_dev_gen(const RtRayGenerator& g)
     return d;
 }
 
-int check_common(const rt_scene* scene, RtSettings st)
+// HIP's current device is per host thread: every entry point that touches the device selects the context's device first
+// (a caller may legally call from a thread other than the one that ran rt_hip_init).  Called with g_mu held.
+int select_device()
 {
     if (!g_ctx.ready) return fail(RT_ERR_NOT_INIT, "rt_hip_init() has not been called");
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    return RT_OK;
+}
+
+int check_common(const rt_scene* scene, RtSettings st)
+{
+    if (int rc = select_device()) return rc;
     if (!scene) return fail(RT_ERR_INVALID, "scene is null");
     if (!(st.max_bounces < (1u << 20))) return fail(RT_ERR_INVALID, "max_bounces out of range");
+    return RT_OK;
+}
+
+// Device-side ordering between consecutive calls that use different streams (the context's scratch is shared).
+int order_after_previous(hipStream_t stream)
+{
+    if (g_ctx.last_valid && g_ctx.last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, g_ctx.last_done, 0));
+    return RT_OK;
+}
+int mark_enqueued(hipStream_t stream)
+{
+    HIP_TRY(hipEventRecord(g_ctx.last_done, stream));
+    g_ctx.last_stream = stream;
+    g_ctx.last_valid = true;
+    return RT_OK;
+}
+
+// cell_begin + (cell_count - 1) * cell_step < n_cells without overflow (cell_count >= 1, cell_step >= 1)
+bool cell_range_ok(uint64_t cell_begin, uint64_t cell_count, uint64_t cell_step, uint64_t n_cells)
+{
+    return cell_begin < n_cells && (cell_count - 1) <= (n_cells - 1 - cell_begin) / cell_step;
+}
+
+// Argument checks shared by rt_hip_render and rt_hip_render_dev (everything but the buffers).
+int check_render_args(const RtRayGenerator* gen, uint32_t spp, uint64_t cell_begin, uint64_t cell_count, uint64_t cell_step)
+{
+    if (!gen) return fail(RT_ERR_INVALID, "gen must not be null");
+    if (gen->kind > RT_GEN_PROJECTOR) return fail(RT_ERR_INVALID, "unknown generator kind");
+    if (gen->count_u == 0 || gen->count_v == 0 || spp == 0) return fail(RT_ERR_INVALID, "count_u, count_v and spp must be > 0");
+    if (cell_count == 0) return RT_OK;
+    if (cell_count > 0x7fffffffull) return fail(RT_ERR_INVALID, "cell_count exceeds 2^31-1 per call");
+    if (cell_step == 0) return fail(RT_ERR_INVALID, "cell_step must be > 0");
+    if (!cell_range_ok(cell_begin, cell_count, cell_step, (uint64_t)gen->count_u * gen->count_v))
+        return fail(RT_ERR_INVALID, "cell range exceeds count_u*count_v");
     return RT_OK;
 }
 
@@ -152,10 +200,56 @@ double pinhole_rho(const rt::DevGen& g)
     return (3.0 * G + 7.0 * M) / dmin;  // NaN / inf when nn == 0 or dmin == 0
 }
 
-int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream, const rt_scene* scene)
+// Device scratch a launch uses beyond the caller's inputs and outputs.
+//   fixed == false: the context's grow-only hipMalloc'ed buffers (every entry point but the no-alloc one);
+//   fixed == true : regions of the static device array of rt_scratch.hip; the byte counts are limits, nothing is allocated.
+struct Workspace {
+    bool fixed;
+    unsigned long long* next_unit;
+    unsigned long long* fb_q;
+    size_t fb_q_bytes;
+    uint32_t* secq;
+    size_t secq_bytes;
+    float4* prim_table;
+    size_t prim_table_bytes;
+};
+
+Workspace context_workspace()
 {
-    unsigned idx = g_ctx.next_counter++ % kCounterRing;
-    p.next_unit = g_ctx.counters + idx;
+    Workspace w{};
+    w.fixed = false;
+    w.next_unit = g_ctx.counters + (g_ctx.next_counter++ % kCounterRing);
+    w.fb_q = g_ctx.fb_q;
+    w.fb_q_bytes = g_ctx.fb_q_bytes;
+    w.secq = g_ctx.secq;
+    w.secq_bytes = g_ctx.secq_bytes;
+    w.prim_table = g_ctx.prim_table;
+    w.prim_table_bytes = g_ctx.prim_table_bytes;
+    return w;
+}
+
+// Make sure a scratch buffer holds `need` bytes: grow the context's buffer, or refuse when the workspace is fixed.
+template <class T>
+int ensure_scratch(Workspace& w, T*& buf, size_t& have, T*& ctx_buf, size_t& ctx_have, size_t need, const char* what)
+{
+    if (need <= have) return RT_OK;
+    if (w.fixed)
+        return fail(RT_ERR_UNSUPPORTED, std::string(what) + " needs " + std::to_string(need) +
+                                            " bytes, the fixed workspace holds " + std::to_string(have));
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(ctx_buf);
+    ctx_buf = nullptr;
+    ctx_have = 0;
+    HIP_TRY(hipMalloc((void**)&ctx_buf, need));
+    ctx_have = need;
+    buf = ctx_buf;
+    have = need;
+    return RT_OK;
+}
+
+int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream, const rt_scene* scene, Workspace& ws)
+{
+    p.next_unit = ws.next_unit;
     p.total_segments = d_total;
     HIP_TRY(hipMemsetAsync(p.next_unit, 0, sizeof(unsigned long long), stream));
     if (d_total) HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), stream));
@@ -174,30 +268,49 @@ int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream,
             if (v > c2) c2 = v;
         }
         p.prim_margin = (float)(c2 * 64.0 * 0x1p-24 * (1.0 + 1e-6));
-        const size_t need = rt::pinhole_secq_bytes(p, g_ctx.n_cu);
-        if (need > g_ctx.secq_bytes) {
-            HIP_TRY(hipDeviceSynchronize());
-            (void)hipFree(g_ctx.secq);
-            g_ctx.secq = nullptr;
-            g_ctx.secq_bytes = 0;
-            HIP_TRY(hipMalloc((void**)&g_ctx.secq, need));
-            g_ctx.secq_bytes = need;
-        }
-        p.secq = g_ctx.secq;
-        const size_t tneed = rt::pinhole_table_bytes(p);
-        if (tneed > g_ctx.prim_table_bytes) {
-            HIP_TRY(hipDeviceSynchronize());
-            (void)hipFree(g_ctx.prim_table);
-            g_ctx.prim_table = nullptr;
-            g_ctx.prim_table_bytes = 0;
-            HIP_TRY(hipMalloc((void**)&g_ctx.prim_table, tneed));
-            g_ctx.prim_table_bytes = tneed;
-        }
-        p.prim_table = g_ctx.prim_table;
-        HIP_TRY(rt::launch_pinhole(p, g_ctx.n_cu, stream));
+        if (int rc = ensure_scratch(ws, ws.secq, ws.secq_bytes, g_ctx.secq, g_ctx.secq_bytes, rt::pinhole_secq_bytes(p, g_ctx.n_cu),
+                                    "the continuing-ray rings"))
+            return rc;
+        p.secq = ws.secq;
+        if (int rc = ensure_scratch(ws, ws.prim_table, ws.prim_table_bytes, g_ctx.prim_table, g_ctx.prim_table_bytes,
+                                    rt::pinhole_table_bytes(p), "the streamed sphere table"))
+            return rc;
+        p.prim_table = ws.prim_table;
+        HIP_TRY(rt::launch_pinhole(p, g_ctx.n_cu, g_ctx.device, stream));
     } else {
-        HIP_TRY(rt::launch_trace(p, g_ctx.n_cu, stream));
+        HIP_TRY(rt::launch_trace(p, g_ctx.n_cu, g_ctx.device, stream));
     }
+    return RT_OK;
+}
+
+// rt_hip_render_dev: everything after the argument checks (g_mu held, device selected).
+int render_enqueue(const rt_scene* scene, const RtRayGenerator* gen, uint32_t spp, RtSettings settings, uint64_t seed, uint64_t cell_begin,
+                   uint64_t cell_count, uint64_t cell_step, float* d_fb, int32_t* d_first_id, float* d_first_t, uint32_t* d_seg_count,
+                   uint64_t* d_total_segments, hipStream_t hs, Workspace& ws)
+{
+    rt::TraceParams p{};
+    p.sc = scene->dev;
+    p.rays = nullptr;
+    p.gen = make_dev_gen(*gen);
+    p.spp = spp;
+    p.unit_samples = rt::kUnitSamples;
+    p.units_per_cell = (spp + rt::kUnitSamples - 1) / rt::kUnitSamples;
+    p.cell_count = (uint32_t)cell_count;
+    p.cell_begin = cell_begin;
+    p.cell_step = cell_step;
+    p.st = settings;
+    p.seed = seed;
+    // fixed-point accumulation scratch, shared by every call that uses the same workspace
+    const size_t need = sizeof(unsigned long long) * 4 * cell_count;  // {x, y, z, segments} per cell
+    if (int rc = ensure_scratch(ws, ws.fb_q, ws.fb_q_bytes, g_ctx.fb_q, g_ctx.fb_q_bytes, need, "the fixed-point framebuffer")) return rc;
+    HIP_TRY(hipMemsetAsync(ws.fb_q, 0, need, hs));
+    p.fb_q = ws.fb_q;
+    p.first_id = d_first_id;
+    p.first_t = d_first_t;
+    p.seg_count = d_seg_count;
+    p.scan_mode = g_scan_mode;
+    if (int rc = enqueue(p, (unsigned long long*)d_total_segments, hs, scene, ws)) return rc;
+    HIP_TRY(rt::launch_finalize(ws.fb_q, d_fb, d_seg_count, cell_count, spp, hs));
     return RT_OK;
 }
 
@@ -212,21 +325,26 @@ int rt_hip_init(int device_ordinal)
     std::lock_guard<std::mutex> lk(g_mu);
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
-    if (device_ordinal < 0 || device_ordinal >= n) return fail(RT_ERR_INVALID, "device ordinal out of range");
+    if (device_ordinal < 0 || device_ordinal >= n || device_ordinal >= rt::kMaxDevices) return fail(RT_ERR_INVALID, "device ordinal out of range");
     HIP_TRY(hipSetDevice(device_ordinal));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(RT_ERR_UNSUPPORTED, std::string("librt_hip.so is built for gfx950 only, device is ") + prop.gcnArchName);
     if (g_ctx.ready && g_ctx.device != device_ordinal) {
+        (void)hipSetDevice(g_ctx.device);  // the old context's memory lives on the old device
+        (void)hipDeviceSynchronize();
         (void)hipFree(g_ctx.counters);
         (void)hipFree(g_ctx.fb_q);
         (void)hipFree(g_ctx.secq);
         (void)hipFree(g_ctx.prim_table);
+        if (g_ctx.last_done) (void)hipEventDestroy(g_ctx.last_done);
         g_ctx = Context{};
+        HIP_TRY(hipSetDevice(device_ordinal));
     }
     if (!g_ctx.ready) {
         HIP_TRY(hipMalloc((void**)&g_ctx.counters, kCounterRing * sizeof(unsigned long long)));
+        HIP_TRY(hipEventCreateWithFlags(&g_ctx.last_done, hipEventDisableTiming));
         g_ctx.device = device_ordinal;
         g_ctx.n_cu = prop.multiProcessorCount;
         g_ctx.ready = true;
@@ -238,11 +356,13 @@ void rt_hip_shutdown(void)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_ctx.ready) {
+        (void)hipSetDevice(g_ctx.device);
         (void)hipDeviceSynchronize();
         (void)hipFree(g_ctx.counters);
         (void)hipFree(g_ctx.fb_q);
         (void)hipFree(g_ctx.secq);
         (void)hipFree(g_ctx.prim_table);
+        if (g_ctx.last_done) (void)hipEventDestroy(g_ctx.last_done);
         g_ctx = Context{};
     }
 }
@@ -287,7 +407,7 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     std::vector<rt::BvhNode> bvh_nodes;
     std::vector<rt::TriDev> tris;
     std::vector<uint32_t> mesh_roots(desc->n_meshes, rt::kNoMesh);
-    if (!g_ctx.ready) return fail(RT_ERR_NOT_INIT, "rt_hip_init() has not been called");
+    if (int rc = select_device()) return rc;
     if (!out_scene || (!objects && n_objects) || (!shape_nodes && n_shape_nodes)) return fail(RT_ERR_INVALID, "null argument");
     if (n_objects >= (1ull << 23)) return fail(RT_ERR_INVALID, "too many objects (limit 2^23)");
     *out_scene = nullptr;
@@ -296,6 +416,7 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     std::vector<int32_t> sph_obj, pl_obj;
     std::vector<uint2> obj_mat(n_objects);
     std::vector<uint32_t> obj_shape(n_objects);
+    std::vector<int32_t> obj_cx(n_objects, -1);
     std::vector<rt::CxNode> cx_nodes;
     std::vector<rt::CxObject> cx_objs;
     double c2max = 0.0;
@@ -337,6 +458,7 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
             std::memcpy(co.m, m.c, sizeof co.m);
             std::memcpy(co.minv, mi.c, sizeof co.minv);
             cx_nodes.insert(cx_nodes.end(), pr.nodes.begin(), pr.nodes.end());
+            obj_cx[k] = (int32_t)cx_objs.size();
             cx_objs.push_back(co);
             obj_geom[k] = make_float4(px, py, pz, 0);
             obj_aux[k] = make_float4(0, 0, 0, 0);
@@ -389,6 +511,7 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     up(obj_aux, &d.obj_aux);
     up(obj_mat, &d.obj_mat);
     up(obj_shape, &d.obj_shape);
+    up(obj_cx, &d.obj_cx);
     up(cx_nodes, &d.cx_nodes);
     up(cx_objs, &d.cx_objs);
     up(bvh_nodes, &d.bvh_nodes);
@@ -412,6 +535,7 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
 void rt_hip_scene_destroy(rt_scene* scene)
 {
     std::lock_guard<std::mutex> lk(g_mu);
+    if (g_ctx.ready) (void)hipSetDevice(g_ctx.device);
     free_scene(scene);
 }
 
@@ -450,7 +574,10 @@ int rt_hip_simulate_dev(const rt_scene* scene, const RtRay* d_rays, uint64_t n_r
     p.n_points = d_n_points;
     p.records = d_records;
     p.scan_mode = g_scan_mode;
-    return enqueue(p, (unsigned long long*)d_total_segments, (hipStream_t)stream, scene);
+    if (int rc = order_after_previous((hipStream_t)stream)) return rc;
+    Workspace ws = context_workspace();
+    if (int rc = enqueue(p, (unsigned long long*)d_total_segments, (hipStream_t)stream, scene, ws)) return rc;
+    return mark_enqueued((hipStream_t)stream);
 }
 
 int rt_hip_simulate(const rt_scene* scene, const RtRay* rays, uint64_t n_rays, RtSettings settings, uint64_t seed,
@@ -516,48 +643,17 @@ int rt_hip_render_dev(const rt_scene* scene, const RtRayGenerator* gen, uint32_t
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (int rc = check_common(scene, settings)) return rc;
-    if (!gen || !d_fb) return fail(RT_ERR_INVALID, "gen / fb must not be null");
-    if (gen->kind > RT_GEN_PROJECTOR) return fail(RT_ERR_INVALID, "unknown generator kind");
-    if (gen->count_u == 0 || gen->count_v == 0 || spp == 0) return fail(RT_ERR_INVALID, "count_u, count_v and spp must be > 0");
+    if (!d_fb) return fail(RT_ERR_INVALID, "gen / fb must not be null");
+    if (int rc = check_render_args(gen, spp, cell_begin, cell_count, cell_step)) return rc;
     if (cell_count == 0) return RT_OK;
-    if (cell_count > 0x7fffffffull) return fail(RT_ERR_INVALID, "cell_count exceeds 2^31-1 per call");
-    if (cell_step == 0) return fail(RT_ERR_INVALID, "cell_step must be > 0");
-    const uint64_t n_cells = (uint64_t)gen->count_u * gen->count_v;
-    if (cell_begin + (cell_count - 1) * cell_step >= n_cells) return fail(RT_ERR_INVALID, "cell range exceeds count_u*count_v");
     if (settings.max_bounces == 0) return fail(RT_ERR_INVALID, "max_bounces == 0 is handled by the host entry point only");
-    rt::TraceParams p{};
-    p.sc = scene->dev;
-    p.rays = nullptr;
-    p.gen = make_dev_gen(*gen);
-    p.spp = spp;
-    p.unit_samples = rt::kUnitSamples;
-    p.units_per_cell = (spp + rt::kUnitSamples - 1) / rt::kUnitSamples;
-    p.cell_count = (uint32_t)cell_count;
-    p.cell_begin = cell_begin;
-    p.cell_step = cell_step;
-    p.st = settings;
-    p.seed = seed;
-    // fixed-point accumulation scratch (grow-only; calls on a context are serialised, see rt_hip.h)
-    const size_t need = sizeof(unsigned long long) * 3 * cell_count;
-    if (need > g_ctx.fb_q_bytes) {
-        HIP_TRY(hipDeviceSynchronize());
-        (void)hipFree(g_ctx.fb_q);
-        g_ctx.fb_q = nullptr;
-        g_ctx.fb_q_bytes = 0;
-        HIP_TRY(hipMalloc((void**)&g_ctx.fb_q, need));
-        g_ctx.fb_q_bytes = need;
-    }
     hipStream_t hs = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(g_ctx.fb_q, 0, need, hs));
-    if (d_seg_count) HIP_TRY(hipMemsetAsync(d_seg_count, 0, sizeof(uint32_t) * cell_count, hs));
-    p.fb_q = g_ctx.fb_q;
-    p.first_id = d_first_id;
-    p.first_t = d_first_t;
-    p.seg_count = d_seg_count;
-    p.scan_mode = g_scan_mode;
-    if (int rc = enqueue(p, (unsigned long long*)d_total_segments, hs, scene)) return rc;
-    HIP_TRY(rt::launch_finalize(g_ctx.fb_q, d_fb, (uint64_t)cell_count * 3, spp, hs));
-    return RT_OK;
+    if (int rc = order_after_previous(hs)) return rc;
+    Workspace ws = context_workspace();
+    if (int rc = render_enqueue(scene, gen, spp, settings, seed, cell_begin, cell_count, cell_step, d_fb, d_first_id, d_first_t, d_seg_count,
+                                d_total_segments, hs, ws))
+        return rc;
+    return mark_enqueued(hs);
 }
 
 int rt_hip_render(const rt_scene* scene, const RtRayGenerator* gen, uint32_t spp, RtSettings settings, uint64_t seed,
@@ -568,7 +664,8 @@ int rt_hip_render(const rt_scene* scene, const RtRayGenerator* gen, uint32_t spp
         std::lock_guard<std::mutex> lk(g_mu);
         if (int rc = check_common(scene, settings)) return rc;
     }
-    if (!gen || !out_fb) return fail(RT_ERR_INVALID, "gen / out_fb must not be null");
+    if (!out_fb) return fail(RT_ERR_INVALID, "gen / out_fb must not be null");
+    if (int rc = check_render_args(gen, spp, cell_begin, cell_count, cell_step)) return rc;
     if (cell_count == 0) {
         if (out_total_segments) *out_total_segments = 0;
         return RT_OK;

@@ -5,10 +5,12 @@
 // Rotated spheres and planes take this path too.
 //
 // Such objects are few, so every lane walks them one after the other after the sphere scan, with the reference's
-// own intersect_all: leaf hit lists, stable sort by t, the in/out state machine, hits.first().  Children are
-// evaluated with t_max = +inf and the object then competes through the same (t, obj_id) key as everything else;
-// compared with the reference's shrinking t_max this can only differ when two child surfaces coincide within
-// the 1e-6 window of csg.rs:33 exactly at the current closest t.
+// own intersect_all: leaf hit lists, stable sort by t, the in/out state machine, hits.first().  The reference hands
+// every object the closest t found so far in list order as t_max (scene.rs:54), and a CSG tree's result can depend on
+// it (a child hit beyond t_max is dropped before the 1e-6 left/right attribution of csg.rs:33 looks for it).  The
+// scan finds the closest sphere / plane of the WHOLE list first, so cx_min_key works out that prefix minimum exactly:
+// it is the running best when that best sits earlier in the list, and otherwise it only matters when a leaf surface
+// lies within a hair of the running best, in which case the lane replays the list in order.
 #pragma once
 #include "rt_device.h"
 
@@ -50,11 +52,10 @@ __device__ __forceinline__ void cx_push_quadric(CxHit* out, int& n, float t, F3 
     ++n;
 }
 
-// One leaf's intersect_all(ray, 0.001, +inf): hits in the order the reference pushes them.
-__device__ __noinline__ int cx_leaf(const CxNode nd, F3 o, F3 d, CxHit* out)
+// One leaf's intersect_all(ray, 0.001, t_max): hits in the order the reference pushes them.
+__device__ __noinline__ int cx_leaf(const CxNode nd, F3 o, F3 d, float t_max, CxHit* out)
 {
     int n = 0;
-    const float inf = __builtin_inff();
     const F3 A = f3(nd.a.x, nd.a.y, nd.a.z), B = f3(nd.b.x, nd.b.y, nd.b.z);
     if (nd.kind == CX_SPHERE) {  // sphere.rs:12-74
         const float radius = nd.a.w;
@@ -66,16 +67,16 @@ __device__ __noinline__ int cx_leaf(const CxNode nd, F3 o, F3 d, CxHit* out)
         if (disc < 0.0f) return 0;
         float sqrtd = __builtin_sqrtf(disc);
         float t1 = (-half_b - sqrtd) / a;
-        if (t1 > kTMin && t1 < inf) cx_push_quadric(out, n, t1, o, d, ((o + t1 * d) - A) / radius);
+        if (t1 > kTMin && t1 < t_max) cx_push_quadric(out, n, t1, o, d, ((o + t1 * d) - A) / radius);
         if (disc > 1e-6f) {
             float t2 = (-half_b + sqrtd) / a;
-            if (t2 > kTMin && t2 < inf) cx_push_quadric(out, n, t2, o, d, ((o + t2 * d) - A) / radius);
+            if (t2 > kTMin && t2 < t_max) cx_push_quadric(out, n, t2, o, d, ((o + t2 * d) - A) / radius);
         }
     } else if (nd.kind == CX_PLANE) {  // plane.rs:12-54
         float denom = dot(B, d);
         if (__builtin_fabsf(denom) < 1e-6f) return 0;
         float t = dot(A - o, B) / denom;
-        if (t < kTMin || inf < t) return 0;  // NaN passes, exactly like the reference's test
+        if (t < kTMin || t_max < t) return 0;  // NaN passes, exactly like the reference's test
         bool front = dot(d, B) < 0.0f;
         out[0].t = t;
         out[0].p = o + t * d;
@@ -83,7 +84,7 @@ __device__ __noinline__ int cx_leaf(const CxNode nd, F3 o, F3 d, CxHit* out)
         out[0].ff = front ? 1u : 0u;
         n = 1;
     } else if (nd.kind == CX_BOX) {  // axis_aligned_box.rs:12-95
-        float tmin = kTMin, tmax = inf;
+        float tmin = kTMin, tmax = t_max;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             float inv_d = 1.0f / comp(d, i);
@@ -136,7 +137,7 @@ __device__ __noinline__ int cx_leaf(const CxNode nd, F3 o, F3 d, CxHit* out)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             float t = ts[k];
-            if (t > kTMin && t < inf) {
+            if (t > kTMin && t < t_max) {
                 F3 p = o + t * d;
                 F3 pma = p - A;
                 float proj = dot(pma, B);
@@ -159,7 +160,7 @@ __device__ __noinline__ int cx_leaf(const CxNode nd, F3 o, F3 d, CxHit* out)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             float t = ts[k];
-            if (t > kTMin && t < inf) {
+            if (t > kTMin && t < t_max) {
                 F3 p = o + t * d;
                 F3 pv = p - A;
                 float m = dot(pv, B);
@@ -367,19 +368,23 @@ __device__ __noinline__ bool mesh_first_hit(const DevScene& sc, BvhLds top, uint
     return true;
 }
 
-// hits.first() of Transform(object).intersect_all(ray, 0.001, +inf), still in the object's local space.
-__device__ __noinline__ bool cx_first_hit(const DevScene& sc, BvhLds top, const CxObject& ob, F3 o, F3 d, float t_limit, CxHit& first)
+// hits.first() of Transform(object).intersect_all(ray, 0.001, t_max), still in the object's local space (t is the same
+// number in both spaces, transform.rs:31).  `near` is set when a leaf surface lies in (w_lo, w_hi].
+__device__ __noinline__ bool cx_first_hit(const DevScene& sc, BvhLds top, const CxObject& ob, F3 o, F3 d, float t_max, float w_lo, float w_hi,
+                                          bool& near, CxHit& first)
 {
     const F3 lo = xf_point(ob.minv, o);
     const F3 ld = xf_vector(ob.minv, d);
-    if (ob.mesh_root != kNoMesh) return mesh_first_hit(sc, top, ob.mesh_root, lo, ld, t_limit, first);
+    // a mesh returns its nearest triangle, which does not depend on t_max below that triangle (no CSG inside a mesh)
+    if (ob.mesh_root != kNoMesh) return mesh_first_hit(sc, top, ob.mesh_root, lo, ld, t_max, first);
     CxHit st[kCxStack][kCxMaxHits];
     int cnt[kCxStack];
     int sp = 0;
     for (uint32_t k = 0; k < ob.n_nodes; ++k) {
         const CxNode nd = sc.cx_nodes[ob.first_node + k];
         if (nd.kind < CX_UNION) {
-            cnt[sp] = cx_leaf(nd, lo, ld, st[sp]);
+            cnt[sp] = cx_leaf(nd, lo, ld, t_max, st[sp]);
+            for (int i = 0; i < cnt[sp]; ++i) near = near || (st[sp][i].t > w_lo && st[sp][i].t <= w_hi);
             ++sp;
         } else {
             CxHit tmp[kCxMaxHits];
@@ -395,15 +400,68 @@ __device__ __noinline__ bool cx_first_hit(const DevScene& sc, BvhLds top, const 
     return true;
 }
 
+// scene.rs:50-62 replayed in list order for objects 0 .. obj_end-1: the closest t the reference holds when it reaches
+// object obj_end.  O(objects) per lane; only runs for the rare ray described at cx_min_key.
+__device__ __noinline__ float cx_prefix_closest(const DevScene& sc, BvhLds top, F3 o, F3 d, int32_t obj_end)
+{
+    float best = __builtin_inff();
+    const float a = dot(d, d);
+    for (int32_t j = 0; j < obj_end; ++j) {
+        const int32_t c = sc.obj_cx[j];
+        if (c >= 0) {
+            CxHit h;
+            bool near = false;
+            if (cx_first_hit(sc, top, sc.cx_objs[c], o, d, best, 0.f, 0.f, near, h) && h.t < best) best = h.t;
+        } else if (sc.obj_shape[j] == RT_SHAPE_SPHERE) {
+            const float4 g = sc.obj_geom[j];
+            float t;
+            if (sphere_first_t(o, d, a, f3(g.x, g.y, g.z), g.w, t) && t < best) best = t;
+        } else {
+            const float4 g = sc.obj_geom[j], n4 = sc.obj_aux[j];
+            const F3 n = f3(n4.x, n4.y, n4.z), lo = o - f3(g.x, g.y, g.z);
+            const float denom = dot(n, d);
+            if (__builtin_fabsf(denom) < 1e-6f) continue;
+            const float t = dot(f3(0.0f, 0.0f, 0.0f) - lo, n) / denom;
+            if (t >= kTMin && t < best) best = t;
+        }
+    }
+    return best;
+}
+
 // Merge every complex object into the running closest-hit key; remember the winner's local hit record.
+//
+// The reference evaluates object K with t_max = tau_K, the closest t among objects 0 .. K-1 (scene.rs:54).  `key` holds
+// the closest of ALL spheres and planes plus the complex objects before K, (t_best, j_best):
+//   * j_best < K (or no hit yet): tau_K == t_best exactly, K is evaluated with it.
+//   * j_best > K: tau_K >= t_best is not known.  K is evaluated with t_max = +inf.  A truncated and an untruncated
+//     evaluation agree on every result hit below tau_K - D * 1e-6 (D = tree depth; hits are processed in t order and
+//     the attribution of csg.rs:33 looks 1e-6 ahead per level), so a first hit at or below w_lo = t_best - kCxWindow
+//     is the reference's.  Otherwise K can only win with a hit in (w_lo, t_best], which must be a leaf surface of K:
+//     if there is none K loses in the reference too; if there is one, tau_K is computed by replaying the list
+//     (cx_prefix_closest) and K is evaluated again with it.
+constexpr float kCxWindow = 1e-4f;
 __device__ __forceinline__ unsigned long long cx_min_key(const DevScene& sc, BvhLds top, F3 o, F3 d, unsigned long long key, CxHit& best, int& best_cx)
 {
+    const float inf = __builtin_inff();
     for (uint32_t k = 0; k < sc.n_cx; ++k) {
+        const CxObject& ob = sc.cx_objs[k];
         CxHit h;
         const uint32_t tbits = (uint32_t)(key >> 32);  // kNoHit has all bits set: no limit yet
-        const float t_limit = tbits > 0x7f800000u ? __builtin_inff() : __uint_as_float(tbits);
-        if (cx_first_hit(sc, top, sc.cx_objs[k], o, d, t_limit, h) && h.t < __builtin_inff()) {  // scene.rs:56; NaN / inf never win
-            unsigned long long kk = pack_key(h.t, sc.cx_objs[k].obj_id);
+        const float t_best = tbits > 0x7f800000u ? inf : __uint_as_float(tbits);
+        const int32_t j_best = (int32_t)(uint32_t)(key & 0xffffffffull);
+        bool hit, near = false;
+        if (key == kNoHit || j_best < ob.obj_id || ob.mesh_root != kNoMesh) {
+            hit = cx_first_hit(sc, top, ob, o, d, t_best, 0.f, 0.f, near, h);
+        } else {
+            const float w_lo = __builtin_fmaf(t_best, -0x1p-21f, t_best) - kCxWindow;  // a window edge, not a reported value
+            hit = cx_first_hit(sc, top, ob, o, d, inf, w_lo, t_best, near, h);
+            if (!(hit && h.t <= w_lo)) {
+                hit = false;
+                if (near) hit = cx_first_hit(sc, top, ob, o, d, cx_prefix_closest(sc, top, o, d, ob.obj_id), 0.f, 0.f, near, h);
+            }
+        }
+        if (hit && h.t < inf) {  // scene.rs:56; NaN / inf never win
+            unsigned long long kk = pack_key(h.t, ob.obj_id);
             if (kk < key) {
                 key = kk;
                 best = h;

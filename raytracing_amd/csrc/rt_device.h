@@ -529,6 +529,62 @@ __device__ __forceinline__ Shade shade_hit(const DevScene& sc, F3 o, F3 d, float
     return h;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Per-cell accumulators: fb_q[cell][4] = {sum x, sum y, sum z, segments} as 64-bit integers (32 bytes per cell).
+// flush_cells adds every flushing lane's (x, y, z, segs) to its cell.  Lanes that sit next to each other in the wave and
+// flush into the same cell (the sample blocks of one cell are dealt to neighbouring lanes; the continuing rays they spawn
+// stay neighbours in the ring) are summed in registers first, and the four words of a cell are then added by four
+// neighbouring lanes of ONE wave instruction, so a cell's record travels as a single 32-byte atomic request instead of
+// up to four scattered ones per path.  Wave-uniform control flow; `stage` is >= 576 dwords of the wave's LDS that
+// nothing else uses during the call (the ray stash: dead between the confirm stage and the next step's set-up).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flush_cells(unsigned long long* fb_q, bool flush, uint32_t cell, unsigned long long x, unsigned long long y,
+                                            unsigned long long z, unsigned long long segs, uint32_t* stage, unsigned lane)
+{
+    const unsigned long long fmask = __ballot(flush);
+    if (!fmask) return;
+    // runs of neighbouring flushing lanes with the same cell
+    const uint32_t key = flush ? cell : 0xffffffffu;  // cell indices stay below 2^31
+    const uint32_t prev = __shfl_up(key, 1, 64);
+    const bool head = flush && (lane == 0 || prev != key);
+    const unsigned long long hmask = __ballot(head);
+    const uint32_t run = flush ? mbcnt64(hmask) + (head ? 1u : 0u) : 0u;  // heads at or before this lane; 0 = not flushing
+    if (!flush) x = y = z = segs = 0;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const uint32_t orun = __shfl_down(run, dlt, 64);
+        const unsigned long long ox = __shfl_down(x, dlt, 64), oy = __shfl_down(y, dlt, 64), oz = __shfl_down(z, dlt, 64),
+                                 os = __shfl_down(segs, dlt, 64);
+        const bool take = flush && lane + dlt < 64 && orun == run;  // runs are contiguous: same run at distance dlt => all between
+        if (take) {
+            x += ox;
+            y += oy;
+            z += oz;
+            segs += os;
+        }
+    }
+    // one staged record per run: {cell} in stage[0..63], {x, y, z, segs} as 8 dwords from stage[64 + 8 e]
+    if (head) {
+        const unsigned e = mbcnt64(hmask);
+        stage[e] = cell;
+        unsigned long long* v = reinterpret_cast<unsigned long long*>(stage + 64 + 8 * e);
+        v[0] = x;
+        v[1] = y;
+        v[2] = z;
+        v[3] = segs;
+    }
+    wave_lds_sync();
+    const unsigned n = (unsigned)__builtin_popcountll(hmask);
+    for (unsigned base = 0; base < n; base += 16) {
+        const unsigned e = base + (lane >> 2), c = lane & 3u;
+        if (e < n) {
+            const unsigned long long v = reinterpret_cast<const unsigned long long*>(stage + 64 + 8 * e)[c];
+            if (v) atomicAdd(fb_q + (uint64_t)stage[e] * 4 + c, v);
+        }
+    }
+    wave_lds_sync();
+}
+
 // q = rint(v * 2^24); a NaN value (a path the reference's own arithmetic turned into NaN, e.g. a ray that
 // started inside a Box, axis_aligned_box.rs:70-95) contributes 0.
 __device__ __forceinline__ unsigned long long quantize(float v) { return v == v ? (unsigned long long)__float2ll_rn(v * 16777216.0f) : 0ull; }

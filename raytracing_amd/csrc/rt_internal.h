@@ -10,6 +10,7 @@ namespace rt {
 constexpr int kTileSpheres = 1024;  // largest sphere table staged in LDS (16 KiB of float4); larger scenes are streamed from L2
 constexpr int kBlockThreads = 256;  // 4 waves
 constexpr uint32_t kUnitSamples = 8;  // samples of one cell traced back to back by one lane (render work unit)
+constexpr int kMaxDevices = 64;     // per-device launch state (function attributes, occupancy) is kept in arrays of this size
 constexpr int kUnroll = 4;          // spheres per scan step; sphere arrays are padded to a multiple
 
 // ---- objects off the scan path (rt_complex.h): post-order node programs evaluated per lane ----
@@ -61,6 +62,7 @@ struct DevScene {
     const float4* obj_aux;    // [n_obj] plane: {nx,ny,nz,0}
     const uint2* obj_mat;     // [n_obj] {material kind, bits of material param}
     const uint32_t* obj_shape;  // [n_obj]
+    const int32_t* obj_cx;      // [n_obj] index into cx_objs for objects off the scan path, -1 for scan-path spheres / planes
     const CxNode* cx_nodes;     // node programs of the complex objects
     const CxObject* cx_objs;    // [n_cx]
     const BvhNode* bvh_nodes;   // all meshes
@@ -91,10 +93,10 @@ struct TraceParams {
     uint64_t path_id_base;
     RtSettings st;
     uint64_t seed;
-    unsigned long long* fb_q;  // [cell_count*3] fixed-point sums (2^-24), zeroed by the launcher
+    unsigned long long* fb_q;  // [cell_count][4] = {x, y, z fixed-point sums (2^-24), segment count}, zeroed by the launcher
     int32_t* first_id;
     float* first_t;
-    uint32_t* seg_count;
+    uint32_t* seg_count;  // written by the finalize kernel from fb_q[cell][3]; the trace kernels only test it for null
     float* points;
     uint32_t* n_points;
     RtBounceRecord* records;
@@ -112,12 +114,13 @@ struct TraceParams {
 constexpr unsigned kSecCap = 256;    // entries per wave ring (a primary step adds <= 128 to a residue < 128)
 constexpr unsigned kSecFields = 10;  // o.xyz d.xyz ior cell sample bounce
 
-// Launches the trace kernel on `stream`; d_work = {unsigned long long total_segments; unsigned next_cell} scratch.
-hipError_t launch_trace(const TraceParams& p, int n_cu, hipStream_t stream);
+
+// Launches the trace kernel on `stream` of `device` (the current device; per-device launch state is keyed by it).
+hipError_t launch_trace(const TraceParams& p, int n_cu, int device, hipStream_t stream);
 // Shared-origin (Projector) specialisation. secq must hold pinhole_secq_bytes(), prim_table pinhole_table_bytes().
-hipError_t launch_pinhole(const TraceParams& p, int n_cu, hipStream_t stream);
+hipError_t launch_pinhole(const TraceParams& p, int n_cu, int device, hipStream_t stream);
 size_t pinhole_secq_bytes(const TraceParams& p, int n_cu);
 size_t pinhole_table_bytes(const TraceParams& p);
-hipError_t launch_finalize(const unsigned long long* fb_q, float* fb, uint64_t n_values, uint32_t spp, hipStream_t stream);
+hipError_t launch_finalize(const unsigned long long* fb_q, float* fb, uint32_t* seg_count, uint64_t n_cells, uint32_t spp, hipStream_t stream);
 
 }  // namespace rt

@@ -245,19 +245,19 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
                 s[r].live = false;
                 // fixed-point accumulation (DESIGN.md "path value"): order-independent, so units of one cell
                 // may finish in any order on any lane / GPU and the sum is still bit-identical
-                s[r].accx += (unsigned long long)__float2ll_rn(value.x * 16777216.0f);
-                s[r].accy += (unsigned long long)__float2ll_rn(value.y * 16777216.0f);
-                s[r].accz += (unsigned long long)__float2ll_rn(value.z * 16777216.0f);
+                s[r].accx += quantize(value.x);
+                s[r].accy += quantize(value.y);
+                s[r].accz += quantize(value.z);
                 if (p.n_points) p.n_points[s[r].m] = s[r].np;
                 ++s[r].sample;
                 if (s[r].sample == s[r].sample_end) {
-                    if (p.fb_q) {
-                        unsigned long long* q = p.fb_q + (uint64_t)s[r].m * 3;
+                    if (p.fb_q) {  // {x, y, z, segments} per cell (rt_device.h flush_cells)
+                        unsigned long long* q = p.fb_q + (uint64_t)s[r].m * 4;
                         if (s[r].accx) atomicAdd(q + 0, s[r].accx);
                         if (s[r].accy) atomicAdd(q + 1, s[r].accy);
                         if (s[r].accz) atomicAdd(q + 2, s[r].accz);
+                        atomicAdd(q + 3, (unsigned long long)s[r].segs);
                     }
-                    if (p.seg_count) atomicAdd(p.seg_count + s[r].m, s[r].segs);
                     s[r].m = 0xffffffffu;
                 }
             }
@@ -275,11 +275,17 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
 
 }  // namespace
 
-// fb = sum_q / (spp * 2^24), IEEE f64 division rounded once to f32
-__global__ void finalize_kernel(const unsigned long long* __restrict__ q, float* __restrict__ fb, uint64_t n, double denom)
+// fb = sum_q / (spp * 2^24), IEEE f64 division rounded once to f32; seg_count = the cell's fourth accumulator
+__global__ void finalize_kernel(const unsigned long long* __restrict__ q, float* __restrict__ fb, uint32_t* __restrict__ seg_count, uint64_t n_cells,
+                                double denom)
 {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) fb[i] = (float)((double)q[i] / denom);
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one lane per accumulator word
+    if (i >= n_cells * 4) return;
+    const uint64_t cell = i >> 2;
+    const unsigned c = (unsigned)(i & 3);
+    const unsigned long long v = q[i];
+    if (c < 3) fb[cell * 3 + c] = (float)((double)v / denom);
+    else if (seg_count) seg_count[cell] = (uint32_t)v;
 }
 
 template <class K>
@@ -295,10 +301,13 @@ static int blocks_per_cu(K kernel)
 }
 
 template <int MODE, bool STREAM, bool CX>
-static hipError_t launch_trace_t(const TraceParams& p, int n_cu, hipStream_t stream)
+static hipError_t launch_trace_t(const TraceParams& p, int n_cu, int device, hipStream_t stream)
 {
     constexpr int R = 2;
-    static const int occ = blocks_per_cu(trace_kernel<R, MODE, STREAM, CX>);
+    static int occ_dev[kMaxDevices] = {};  // per device (the query runs on the current device); callers hold the library mutex
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (!occ_dev[device]) occ_dev[device] = blocks_per_cu(trace_kernel<R, MODE, STREAM, CX>);
+    const int occ = occ_dev[device];
     // persistent grid: exactly the resident capacity (every block pulls units until the counter runs out),
     // never more blocks than the work can feed
     const uint64_t slots_per_block = (uint64_t)kBlockThreads * R;
@@ -310,23 +319,23 @@ static hipError_t launch_trace_t(const TraceParams& p, int n_cu, hipStream_t str
     return hipGetLastError();
 }
 
-hipError_t launch_trace(const TraceParams& p, int n_cu, hipStream_t stream)
+hipError_t launch_trace(const TraceParams& p, int n_cu, int device, hipStream_t stream)
 {
     const bool stream_table = p.sc.n_sph_pad > (uint32_t)kTileSpheres;
     const bool cx = p.sc.n_cx > 0;
     if (p.scan_mode == 0) {
-        if (cx) return stream_table ? launch_trace_t<0, true, true>(p, n_cu, stream) : launch_trace_t<0, false, true>(p, n_cu, stream);
-        return stream_table ? launch_trace_t<0, true, false>(p, n_cu, stream) : launch_trace_t<0, false, false>(p, n_cu, stream);
+        if (cx) return stream_table ? launch_trace_t<0, true, true>(p, n_cu, device, stream) : launch_trace_t<0, false, true>(p, n_cu, device, stream);
+        return stream_table ? launch_trace_t<0, true, false>(p, n_cu, device, stream) : launch_trace_t<0, false, false>(p, n_cu, device, stream);
     }
-    if (cx) return stream_table ? launch_trace_t<1, true, true>(p, n_cu, stream) : launch_trace_t<1, false, true>(p, n_cu, stream);
-    return stream_table ? launch_trace_t<1, true, false>(p, n_cu, stream) : launch_trace_t<1, false, false>(p, n_cu, stream);
+    if (cx) return stream_table ? launch_trace_t<1, true, true>(p, n_cu, device, stream) : launch_trace_t<1, false, true>(p, n_cu, device, stream);
+    return stream_table ? launch_trace_t<1, true, false>(p, n_cu, device, stream) : launch_trace_t<1, false, false>(p, n_cu, device, stream);
 }
 
-hipError_t launch_finalize(const unsigned long long* fb_q, float* fb, uint64_t n_values, uint32_t spp, hipStream_t stream)
+hipError_t launch_finalize(const unsigned long long* fb_q, float* fb, uint32_t* seg_count, uint64_t n_cells, uint32_t spp, hipStream_t stream)
 {
     const unsigned threads = 256;
-    const unsigned blocks = (unsigned)((n_values + threads - 1) / threads);
-    hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(threads), 0, stream, fb_q, fb, n_values, (double)spp * 16777216.0);
+    const unsigned blocks = (unsigned)((n_cells * 4 + threads - 1) / threads);
+    hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(threads), 0, stream, fb_q, fb, seg_count, n_cells, (double)spp * 16777216.0);
     return hipGetLastError();
 }
 

@@ -238,7 +238,9 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
 
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            bool push = false;
+            bool push = false, fl = false;
+            uint32_t fcell = 0;
+            unsigned long long fx = 0, fy = 0, fz = 0, fsegs = 0;
             Shade h;
             h.o_next = ro[r]; h.dn = rd[r]; h.ior = rior[r];
             if (live[r]) {
@@ -287,23 +289,26 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                     }
                     ++usample[r];
                     if (usample[r] == uend[r]) {
-                        unsigned long long* q = p.fb_q + (uint64_t)um[r] * 3;
-                        if (ax[r]) atomicAdd(q + 0, ax[r]);
-                        if (ay[r]) atomicAdd(q + 1, ay[r]);
-                        if (az[r]) atomicAdd(q + 2, az[r]);
-                        if (p.seg_count) atomicAdd(p.seg_count + um[r], usegs[r]);
+                        fl = true;
+                        fcell = um[r];
+                        fx = ax[r];
+                        fy = ay[r];
+                        fz = az[r];
+                        fsegs = usegs[r];
                         um[r] = 0xffffffffu;
                     }
                 } else if (ended) {
                     // a continuing path ends: it has run b segments after its primary one
-                    unsigned long long* q = p.fb_q + (uint64_t)rm[r] * 3;
-                    const unsigned long long qx = quantize(value.x), qy = quantize(value.y), qz = quantize(value.z);
-                    if (qx) atomicAdd(q + 0, qx);
-                    if (qy) atomicAdd(q + 1, qy);
-                    if (qz) atomicAdd(q + 2, qz);
-                    if (p.seg_count) atomicAdd(p.seg_count + rm[r], b);
+                    fl = true;
+                    fcell = rm[r];
+                    fx = quantize(value.x);
+                    fy = quantize(value.y);
+                    fz = quantize(value.z);
+                    fsegs = b;
                 }
             }
+            // per-cell sums: neighbouring lanes of one cell are combined first (rt_device.h flush_cells)
+            flush_cells(p.fb_q, fl, fcell, fx, fy, fz, fsegs, reinterpret_cast<uint32_t*>(&w.stash[0][0]), lane);
             // append continuing rays to the ring (wave-uniform control flow)
             const unsigned long long pm = __ballot(push);
             if (pm) {
@@ -388,12 +393,14 @@ size_t pinhole_secq_bytes(const TraceParams& p, int n_cu)
 size_t pinhole_table_bytes(const TraceParams& p) { return stream_mode(p) ? (size_t)p.sc.n_sph_pad * sizeof(float4) : 0; }
 
 template <bool CX>
-static hipError_t launch_pinhole_t(const TraceParams& p_in, int n_cu, hipStream_t stream)
+static hipError_t launch_pinhole_t(const TraceParams& p_in, int n_cu, int device, hipStream_t stream)
 {
     TraceParams p = p_in;
     p.bvh_lds_nodes = CX ? (stream_mode(p) ? bvh_lds_fit<true>(p) : bvh_lds_fit<false>(p)) : 0;
     const unsigned grid = pinhole_grid(p, n_cu);
-    static bool attr_set = false;  // per instantiation; one device per process (rt_hip_init)
+    static bool attr_set_dev[kMaxDevices] = {};  // per instantiation and device (function attributes are per device); callers hold the library mutex
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    bool& attr_set = attr_set_dev[device];
     if (!attr_set) {
         const int max_dyn = (int)(kTileSpheres * sizeof(float4) * 2 + kBvhLdsNodes * sizeof(BvhNode));
         hipError_t e = hipFuncSetAttribute((const void*)pinhole_kernel<kR, false, CX>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
@@ -414,9 +421,9 @@ static hipError_t launch_pinhole_t(const TraceParams& p_in, int n_cu, hipStream_
     return hipGetLastError();
 }
 
-hipError_t launch_pinhole(const TraceParams& p, int n_cu, hipStream_t stream)
+hipError_t launch_pinhole(const TraceParams& p, int n_cu, int device, hipStream_t stream)
 {
-    return p.sc.n_cx > 0 ? launch_pinhole_t<true>(p, n_cu, stream) : launch_pinhole_t<false>(p, n_cu, stream);
+    return p.sc.n_cx > 0 ? launch_pinhole_t<true>(p, n_cu, device, stream) : launch_pinhole_t<false>(p, n_cu, device, stream);
 }
 
 }  // namespace rt

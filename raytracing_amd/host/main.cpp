@@ -30,14 +30,40 @@
 
 namespace {
 
-// Rust `impl Display for f32`: shortest digits that round-trip, positional notation, no trailing ".0".
+// Rust `impl Display for f32`: shortest digits that round-trip, positional notation (never an exponent), no trailing ".0".
+// std::to_chars' shortest *scientific* form gives exactly those digits; they are then laid out positionally, padded with
+// zeros on either side of the point (1234567936f32 -> "1234568000", 1e-7f -> "0.0000001"), as Rust does.
 std::string format_f32(float x)
 {
     if (std::isnan(x)) return "NaN";
     if (std::isinf(x)) return x > 0 ? "inf" : "-inf";
-    char buf[128];
-    auto r = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::fixed);
-    return std::string(buf, r.ptr);
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::scientific);
+    std::string sci(buf, r.ptr);  // [-]d[.ddd]e[+-]XX
+    std::string out;
+    size_t pos = 0;
+    if (sci[0] == '-') {
+        out = "-";
+        pos = 1;
+    }
+    const size_t e = sci.find('e');
+    std::string digits;
+    for (size_t k = pos; k < e; ++k)
+        if (sci[k] != '.') digits += sci[k];
+    const int exp10 = std::atoi(sci.c_str() + e + 1);  // value = d.ddd * 10^exp10
+    const int n = (int)digits.size();
+    if (digits == "0") return out + "0";
+    if (exp10 >= n - 1) {  // integer: digits followed by zeros
+        out += digits;
+        out.append((size_t)(exp10 - (n - 1)), '0');
+    } else if (exp10 >= 0) {  // point inside the digit string
+        out += digits.substr(0, (size_t)exp10 + 1) + "." + digits.substr((size_t)exp10 + 1);
+    } else {  // 0.000ddd
+        out += "0.";
+        out.append((size_t)(-exp10 - 1), '0');
+        out += digits;
+    }
+    return out;
 }
 
 int fail_rt(const char* what)
@@ -201,6 +227,15 @@ int main(int argc, char** argv)
         else if (a == "--seed" && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 0);
         else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (a == "--dump") dump_only = true;
+        else if (a == "--format-f32") {  // diagnostic: print the CSV text of each following f32 bit pattern (hex), one per line
+            for (++i; i < argc; ++i) {
+                const uint32_t bits = (uint32_t)std::strtoul(argv[i], nullptr, 16);
+                float f;
+                std::memcpy(&f, &bits, 4);
+                std::printf("%s\n", format_f32(f).c_str());
+            }
+            return 0;
+        }
         else if (a == "--render" && i + 1 < argc) render_spp = (uint32_t)std::strtoul(argv[++i], nullptr, 0);
         else if (a == "--generator" && i + 1 < argc) gen_index = std::strtoul(argv[++i], nullptr, 0);
         else if (a == "--frames" && i + 1 < argc) frames_dir = argv[++i];

@@ -74,3 +74,24 @@ def test_header_is_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and out.stdout.split() == ["44", "28", "52"], (out.stdout, out.stderr)
+
+
+def test_entry_points_are_callable_from_any_thread():
+    """HIP's current device is per host thread and the error text is per thread: a call from a second thread must behave like
+    one from the first (here, without a GPU: the same NOT_INIT refusal, its message visible to the calling thread only)."""
+    import threading
+
+    L = _lib.lib()
+    out = {}
+
+    def worker():
+        h = C.c_void_p()
+        objs = np.zeros(1, abi.OBJECT_DTYPE)
+        out["rc"] = L.rt_hip_scene_create(abi.ptr(objs), 1, C.byref(h))
+        out["msg"] = L.rt_hip_last_error()
+
+    assert L.rt_hip_set_scan_mode(0) == abi.RT_OK
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert out["rc"] == abi.RT_ERR_NOT_INIT and b"rt_hip_init" in out["msg"]

@@ -367,6 +367,32 @@ def test_complex_objects_random_rays(engine):
     assert same(pts, opts)
 
 
+def test_csg_sees_the_closest_t_of_the_objects_before_it(engine):
+    """scene.rs:54: a CSG tree is evaluated with t_max = closest t of the objects earlier in the list, which decides the 1e-6
+    left/right attribution of csg.rs:33 when child surfaces nearly coincide there (tests/test_oracle.py::
+    test_csg_result_depends_on_the_closest_t_so_far derives the expected winners by hand).  The kernels find the closest
+    sphere / plane of the whole list first, so this is the case that needs the exact prefix minimum."""
+    from test_oracle import _window_scene
+
+    nodes, diff, p_at_5, p_at_tb, t_a, t_b = _window_scene()
+    rays = make_rays([(0, 0, 0)] * 70, [(0, 0, 1)] * 70)
+    st = SimulationSettingsConfig(100.0, 1)
+    for objs, want_id, want_t in [([diff], 0, t_b), ([p_at_5, diff], 0, np.float32(5.0)), ([diff, p_at_5], 0, t_b),
+                                  ([p_at_5, diff, p_at_tb], 2, t_b), ([diff, p_at_tb], 0, t_b),
+                                  ([sphere((0, 0, 6), 1.0, abi.RT_MAT_MIRROR), diff, p_at_tb], 2, t_b)]:
+        objs = np.array(objs, dtype=abi.OBJECT_DTYPE)
+        pts, npts, recs = engine.Scene(objs, nodes=nodes).simulate_rays_raw(st, rays=rays, seed=1)
+        opts, onpts, orecs, _ = ob.OracleScene(objs, nodes).simulate(rays, 100.0, 1, seed=1)
+        assert_records_equal(recs, orecs, "csg window")
+        assert np.all(recs["obj_id"][:, 0] == want_id) and np.all(recs["t"][:, 0] == want_t)
+        # the render loop's kernels carry the same per-lane path
+        gen = projector((0.0, 0.0, 0.0), (-0.001, -0.001, 1.0), (0.002, 0.0, 0.0), (0.0, 0.002, 0.0), 1, 1)
+        gen.corner[0], gen.corner[1] = 0.0, 0.0  # the single cell's ray is exactly +z
+        got = engine.Scene(objs, nodes=nodes).render(gen, 2, st, seed=1)
+        want = ob.OracleScene(objs, nodes).render(gen, 2, 100.0, 1, seed=1)
+        assert got[1][0] == want[1][0] == want_id and got[2][0] == want[2][0] == want_t
+
+
 def test_gpu_matches_golden_allshapes(engine):
     g = np.load(os.path.join(GOLD, "allshapes_paths.npz"))
     sc = engine.Scene(g["objects"], nodes=g["nodes"])
@@ -679,3 +705,96 @@ def test_full_resolution_c4_c3_properties(engine, which):
     for c in cells:
         ofb, ofid, oft, oseg, _ = osc.render(g, spp, cfg["infinity_distance"], cfg["max_bounces"], seed=cfg["seed"], cell_begin=int(c), cell_count=1)
         assert ofid[0] == fid[c] and oft[0] == ft[c] and oseg[0] == seg[c] and np.array_equal(ofb[0], fb[c]), int(c)
+
+
+@pytest.mark.parametrize("which", ["c4", "c3"])
+def test_full_spp_cells_against_oracle(engine, which):
+    """BASELINE.json configs[3] / configs[2] at their FULL sample counts (1,024 / 256 spp) on sampled cells, every output
+    bit for bit against the oracle.  C4's cells are taken from the end of the grid, where path_id = cell * spp + s exceeds
+    2^32, so the high counter word of the HalfMirror stream (rt_device.h uniform01, scene.rs:88) is non-zero; a third of
+    the cells are chosen because their primary hit IS a HalfMirror sphere."""
+    cfg = synth.config_c4() if which == "c4" else synth.config_c3()
+    spp = cfg["spp"]
+    assert spp == (1024 if which == "c4" else 256)
+    meshes = cfg.get("meshes")
+    sc = engine.Scene(cfg["objects"], meshes=meshes)
+    osc = ob.OracleScene(cfg["objects"], meshes=meshes)
+    st = SimulationSettingsConfig(cfg["infinity_distance"], cfg["max_bounces"])
+    g = cfg["gen"]
+    n = g.count_u * g.count_v
+    # probe pass (1 spp) over a band of cells to learn what each cell's primary ray hits
+    band = 400_000
+    # C4: columns i = 2000 .. 2185 look into the sphere cloud and already have cell * 1024 >= 2^32 (cell >= 4,194,304)
+    begin = 2000 * g.count_v if which == "c4" else n // 2 - band // 2
+    _, fid, _, _, _ = sc.render(g, 1, st, seed=cfg["seed"], cell_begin=begin, cell_count=band)
+    mats = cfg["objects"]["material_kind"]
+    kind = np.where(fid >= 0, mats[np.clip(fid, 0, None)], 255)
+    rng = np.random.default_rng(4)
+    hm = np.flatnonzero(kind == abi.RT_MAT_HALF_MIRROR)
+    other_hit = np.flatnonzero((kind != abi.RT_MAT_HALF_MIRROR) & (fid >= 0))
+    assert len(hm) >= 10 and len(other_hit) >= 10
+    cells = begin + np.unique(np.concatenate([rng.choice(hm, 10, replace=False), rng.choice(other_hit, 10, replace=False),
+                                              rng.choice(band, 10, replace=False)]))
+    if which == "c4":
+        assert np.all((cells.astype(np.uint64) * np.uint64(spp)) >> np.uint64(32) >= 1)  # 64-bit path ids
+    varied = 0
+    for c in cells:
+        c = int(c)
+        got = sc.render(g, spp, st, seed=cfg["seed"], cell_begin=c, cell_count=1)
+        want = osc.render(g, spp, cfg["infinity_distance"], cfg["max_bounces"], seed=cfg["seed"], cell_begin=c, cell_count=1, threads=4)
+        assert got[1][0] == want[1][0] and got[2][0] == want[2][0], c          # first-hit id and t
+        assert got[3][0] == want[3][0] and got[4] == want[4], c                # segment counts
+        assert np.array_equal(got[0], want[0]), c                              # accumulated pixel
+        if kind[c - begin] == abi.RT_MAT_HALF_MIRROR:
+            # identical primary rays, so the samples differ only through the HalfMirror draws: with a working stream the
+            # cell's segment count is neither "all reflected" nor "all passed"
+            per_path = want[3][0] / spp
+            varied += int(per_path != int(per_path))
+    assert varied >= 5
+    # several cells in one launch, strided (what a rank of the tile-sharded job runs), same sample count
+    b0, step, cnt = int(cells[0]), 4099, 12
+    if b0 + (cnt - 1) * step < n:
+        got = sc.render(g, spp, st, seed=cfg["seed"], cell_begin=b0, cell_count=cnt, cell_step=step)
+        want = osc.render(g, spp, cfg["infinity_distance"], cfg["max_bounces"], seed=cfg["seed"], cell_begin=b0, cell_count=cnt, cell_step=step, threads=8)
+        for a, b in zip(got[:4], want[:4]):
+            assert same(a, b)
+        assert got[4] == want[4]
+
+
+def test_calls_from_another_host_thread_and_stream(engine):
+    """Every entry point selects the init device itself (HIP's current device is per thread), and a _dev call on another
+    stream than its predecessor waits for it: a worker thread rendering on its own stream, interleaved with the main thread's
+    calls on the default stream, gets the same images as a single-threaded run."""
+    import threading
+
+    import torch
+
+    cfg = synth.config_c2(120, 70)
+    sc = engine.Scene(cfg["objects"])
+    st = SimulationSettingsConfig(cfg["infinity_distance"], cfg["max_bounces"])
+    n = 120 * 70
+    want = {seed: sc.render(cfg["gen"], 3, st, seed=seed) for seed in (1, 2)}
+    dev = torch.device("cuda", 0)
+    results, errors = {}, []
+
+    def run(seed, reps):
+        try:
+            stream = torch.cuda.Stream(device=dev)
+            fb = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+            seg = torch.zeros(n, dtype=torch.int32, device=dev)
+            tot = torch.zeros(1, dtype=torch.int64, device=dev)
+            for _ in range(reps):
+                sc.render_dev(cfg["gen"], 3, st, seed, 0, n, 1, fb.data_ptr(), 0, 0, seg.data_ptr(), tot.data_ptr(), stream.cuda_stream)
+            stream.synchronize()
+            results[seed] = (fb.cpu().numpy(), seg.cpu().numpy(), int(tot.item()))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    t = threading.Thread(target=run, args=(2, 6))
+    t.start()
+    run(1, 6)
+    t.join()
+    assert not errors, errors
+    for seed in (1, 2):
+        fb, seg, tot = results[seed]
+        assert np.array_equal(fb, want[seed][0]) and np.array_equal(seg.astype(np.uint32), want[seed][3]) and tot == want[seed][4]

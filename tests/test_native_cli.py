@@ -98,3 +98,25 @@ def test_native_cli_end_to_end(tmp_path):
         text = (tmp_path / "dist" / f"path_{i}.csv").read_text()
         want = "x,y,z\n" + "".join(",".join(format_f32(c) for c in p) + "\n" for p in g["points"][i, : g["n_points"][i]])
         assert text == want  # same bytes as the Python writer, i.e. Rust's f32::to_string() digits
+
+
+def test_native_csv_number_format_matches_rust_display():
+    """cli.rs:21-27 writes `f32::to_string()`: shortest round-trip digits, always positional.  The native writer and the
+    Python mirror must print the same text at every magnitude (1234567936f32 is "1234568000", never "1234567936")."""
+    from raytracing_amd.cli import format_f32
+
+    rng = np.random.default_rng(7)
+    vals = [0.0, -0.0, 1.0, -1.5, 0.001, 1e-7, 1.17549435e-38, 1e-45, 16777216.0, 16777218.0, 1234567936.0, -987654321.0, 1e9, 3.0e10,
+            1e30, -1e30, 3.4028235e38, 24.163, -4.948, 0.1, 123456.789, float("inf"), float("-inf"), float("nan")]
+    vals += list(rng.normal(size=200) * 10.0 ** rng.integers(-12, 38, 200))
+    bits = np.array(vals, np.float32).view(np.uint32)
+    bits = np.concatenate([bits, rng.integers(0, 2**32, 500, dtype=np.uint64).astype(np.uint32)])
+    r = subprocess.run([BIN, "--format-f32"] + [f"{b:08x}" for b in bits], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    got = r.stdout.split("\n")[:-1]
+    assert len(got) == len(bits)
+    for b, text in zip(bits, got):
+        x = np.array([b], np.uint32).view(np.float32)[0]
+        assert text == format_f32(x), (hex(int(b)), text, format_f32(x))
+    assert format_f32(np.float32(1234567936.0)) == "1234568000" and format_f32(np.float32(1e-7)) == "0.0000001"
+    assert format_f32(np.float32(-0.0)) == "-0" and format_f32(np.float32(1e30)) == "1000000000000000000000000000000"

@@ -46,8 +46,18 @@ def test_sphere_kats():
     # tangent: discriminant == 0 -> single root, the `disc > 1e-6` guard suppresses the second (sphere.rs:47)
     t, p, n, ff = ob.sphere_first_hit((0, 1, 0), 1.0, (-5, 0, 0), (1, 0, 0))
     assert t == f32(5.0)
-    # tiny positive discriminant (<= 1e-6) with t1 out of range: no second root
-    assert ob.sphere_first_hit((0, 0, 0), 1.0, (0, 0.9999999, 0), (1, 0, 0), t_min=0.001) is None or True
+    # origin just inside the surface, moving tangentially: oc.y = 1 - 2^-23, c = fl(oc.y^2) - 1 = -2^-22, disc = 2^-22 = 2.4e-7.
+    # t1 = -2^-11 is behind the origin; the second root +2^-11 = 4.9e-4 is in range (t_min = 1e-4 here), but the guard
+    # `discriminant > 1e-6` (sphere.rs:47) suppresses it: the reference reports NO hit
+    assert f32(0.9999999) == f32(1) - f32(2.0 ** -23)
+    assert ob.sphere_first_hit((0, 0, 0), 1.0, (0, 0.9999999, 0), (1, 0, 0), t_min=1e-4) is None
+    # a little deeper inside the discriminant clears the guard and the second root is reported (back face, inverted normal)
+    oc_y = f32(0.999999)
+    disc = f32(0) - f32(f32(oc_y * oc_y) - f32(1))
+    assert disc > f32(1e-6)
+    t, p, n, ff = ob.sphere_first_hit((0, 0, 0), 1.0, (0, 0.999999, 0), (1, 0, 0), t_min=1e-4)
+    assert t == np.sqrt(disc) and t == f32(0.0014235722) and not ff
+    assert np.array_equal(p, np.array([t, oc_y, 0], f32)) and np.array_equal(n, -np.array([t, oc_y, 0], f32))
     # miss and pointing away
     assert ob.sphere_first_hit((0, 5, 0), 1.0, (-5, 0, 0), (1, 0, 0)) is None
     assert ob.sphere_first_hit((0, 0, 0), 1.0, (-3, 0, 0), (-1, 0, 0)) is None
@@ -238,15 +248,26 @@ def test_csg_and_quadric_kats():
     # every child in the state machine, so the reference never sees the lens: mirrored
     assert _first([lens], (0, 0, -10), (0, 0, 1))["obj_id"][0] == -1
     assert _first([lens], (0, 9.5, -10), (0.001, 0, 1))["obj_id"][0] == -1  # outside the aperture cylinder
-    # Cylinder (shape_config.rs:74-103): a ray that crosses the top cap inside the body is seen ...
+    # Cylinder (shape_config.rs:74-103) = (body & cap_top) & cap_bottom, height 4, radius 1.  A ray that starts above the
+    # top cap INSIDE the infinite body (x = -0.5) and descends: x = -0.5 + 0.1 t, y = 10 - t.  Child hits in (0.001, inf):
+    # cap_top t = 8, cap_bottom t = 12, body t = 15 (x = +1; the x = -1 root t = -5 is behind).  Inner CSG, all flags false
+    # at the start (csg.rs:28-29): t = 8 sets in_right (no surface), t = 15 sets in_left -> "enters" the intersection;
+    # the outer CSG likewise accepts t = 15.  So the reference reports the body's EXIT point (1, -5, 0), three units
+    # below the bottom cap, as the cylinder's first surface, back face, normal flipped to -x.  Mirrored, not fixed.
     cyl = shape_object(abi.RT_SHAPE_CYLINDER, (4.0, 1.0), (0, 0, 0), abi.RT_MAT_MIRROR)
     r = _first([cyl], (-0.5, 10, 0), (0.1, -1, 0))
-    assert r["obj_id"][0] == -1 or r["obj_id"][0] == 0
-    # ... while a horizontal ray, which never crosses a cap plane, is NOT (in/out state starts "outside", csg.rs:28-29)
+    assert r["obj_id"][0] == 0 and r["t"][0] == f32(15.0) and r["front_face"][0] == 0
+    assert np.array_equal(r["point"][0], [1, -5, 0]) and np.array_equal(r["normal"][0], [-1, 0, 0])
+    # ... while a horizontal ray, which never crosses a cap plane, never sees it (in/out state starts "outside", csg.rs:28-29)
     assert _first([cyl], (-5, 0, 0), (1, 0, 0))["obj_id"][0] == -1
     # Wedge (wedge.rs): five half-spaces
+    # A ray rising through the wedge's footprint at x = 5 (y = -3 + t, z = 0.01 t) crosses p1 (y = 0) at t = 3, the inclined
+    # p3 at t = 4.34, p4 (z = 2) at t = 200; it is parallel to p2 (x = 0: |denom| < 1e-6 -> None, plane.rs:17) and p5
+    # (z = -2) lies behind it.  csg1 = p1 & p2 toggles in_left only -> None; every later Intersection then has an empty left
+    # list and can never become "inside": the reference does not see the wedge at all, although the ray passes through it.
     wedge = shape_object(abi.RT_SHAPE_WEDGE, (10.0, 8.0, 4.0, 15.0), (0, 0, 0), abi.RT_MAT_GLASS, 1.5)
-    assert _first([wedge], (5, -3, 0), (0, 1, 0.01))["obj_id"][0] in (0, -1)
+    r = _first([wedge], (5, -3, 0), (0, 1, 0.01))
+    assert r["obj_id"][0] == -1 and np.isinf(r["t"][0])
     # Difference(Sphere r=3, Sphere r=1): from outside the first surface is the big sphere, front face
     nodes = np.zeros(3, abi.NODE_DTYPE)
     nodes[0]["shape"], nodes[0]["shape_param"] = abi.RT_SHAPE_SPHERE, (3, 0, 0, 0)
@@ -259,13 +280,54 @@ def test_csg_and_quadric_kats():
     # (x=+3, t = 6 - 0.001) as the surface; then the ray leaves.  Mirrored, not fixed.
     assert rec["obj_id"][:3].tolist() == [0, 0, -1] and abs(rec["t"][0] - 7.0) < 1e-5 and abs(rec["t"][1] - 5.999) < 1e-4
     assert rec["front_face"][0] == 1
-    # from inside the hole the hole's wall is seen with an inverted normal (Difference flips right-hand hits, csg.rs:57-61)
+    # from inside the hole: right hit t = 1 (hole wall) sets in_right, left hit t = 3 sets in_left; "in_left && !in_right"
+    # (csg.rs:39,53) is false before and after both, so neither is a surface: the ray escapes without a hit
     rec = _first([diff], (0, 0, 0), (1, 0, 0), nodes=nodes, max_b=1)
-    assert rec["obj_id"][0] == -1 or rec["front_face"][0] in (0, 1)
+    assert rec["obj_id"][0] == -1 and np.isinf(rec["t"][0])
     # Union(Sphere r=2, Sphere r=1) == the big sphere from outside: inner surfaces are swallowed
     nodes[2]["shape"] = abi.RT_SHAPE_UNION
     rec = _first([tree_object(2, (0, 0, 0), abi.RT_MAT_GLASS, 1.0)], (-10, 0, 0), (1, 0, 0), nodes=nodes, max_b=6)
     assert rec["obj_id"][0] == 0 and abs(rec["t"][0] - 7.0) < 1e-5 and rec["front_face"][0] == 1
+
+
+def _window_scene():
+    """A Difference(Box A, Box B) whose two entry faces lie 9.5e-7 apart in t, straddling t = 5 (box entries along the
+    axis are exact: t = 10 - half_depth), plus planes at exactly t = 5 and at B's entry."""
+    from raytracing_amd.engine import tree_object
+
+    half_a, half_b = np.nextafter(f32(5), f32(0)), np.nextafter(f32(5), f32(10))
+    t_a, t_b = f32(10) - half_a, f32(10) - half_b
+    assert t_b < f32(5) < t_a and t_a - t_b < f32(1e-6)
+    nodes = np.zeros(3, abi.NODE_DTYPE)
+    nodes[0]["shape"], nodes[0]["shape_param"] = abi.RT_SHAPE_BOX, (2, 2, 2 * half_a, 0)
+    nodes[1]["shape"], nodes[1]["shape_param"] = abi.RT_SHAPE_BOX, (2, 2, 2 * half_b, 0)
+    nodes[2]["shape"], nodes[2]["a"], nodes[2]["b"] = abi.RT_SHAPE_DIFFERENCE, 0, 1
+    diff = tree_object(2, (0, 0, 10), abi.RT_MAT_MIRROR)
+    p_at_5 = plane((0, 0, 5), (0, 0, -1), abi.RT_MAT_MIRROR)
+    p_at_tb = plane((0, 0, float(t_b)), (0, 0, -1), abi.RT_MAT_MIRROR)
+    return nodes, diff, p_at_5, p_at_tb, t_a, t_b
+
+
+def test_csg_result_depends_on_the_closest_t_so_far():
+    """scene.rs:54 hands every object the closest t of the objects BEFORE it as t_max, and a CSG result depends on it: a
+    child hit at or beyond t_max is dropped before csg.rs:33 looks for a left hit within 1e-6.  Alone, the Difference's
+    right-hand entry (t_b) is attributed to the left box (its entry t_a is 9.5e-7 later) and becomes a surface; behind a plane
+    at t = 5 (t_b < 5 < t_a) the left list is empty, t_b is a right-hand hit and no surface: the plane wins."""
+    nodes, diff, p_at_5, p_at_tb, t_a, t_b = _window_scene()
+    o, d = (0, 0, 0), (0, 0, 1)
+    r = _first([diff], o, d, nodes=nodes)
+    assert r["obj_id"][0] == 0 and r["t"][0] == t_b and np.array_equal(r["normal"][0], [0, 0, -1])
+    r = _first([p_at_5, diff], o, d, nodes=nodes)
+    assert r["obj_id"][0] == 0 and r["t"][0] == f32(5.0)
+    # the same object placed BEFORE the plane is evaluated with t_max = inf and wins
+    r = _first([diff, p_at_5], o, d, nodes=nodes)
+    assert r["obj_id"][0] == 0 and r["t"][0] == t_b
+    # closest object later in the list than the CSG tree: the tree still sees t_max = 5 (from object 0), yields nothing, and
+    # object 2 wins the tie at t_b that the tree would otherwise have taken with its lower index
+    r = _first([p_at_5, diff, p_at_tb], o, d, nodes=nodes)
+    assert r["obj_id"][0] == 2 and r["t"][0] == t_b
+    r = _first([diff, p_at_tb], o, d, nodes=nodes)
+    assert r["obj_id"][0] == 0 and r["t"][0] == t_b
 
 
 def test_oracle_matches_golden_allshapes():

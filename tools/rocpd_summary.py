@@ -20,3 +20,9 @@ if rows:
     print("## PMC sums per kernel (sum over dispatches and over SE/XCD instances)")
     for k, c, v, n in rows:
         print(f"{k[:70]:70s} {c:28s} {v:22.0f}  dispatches={n}")
+    # dispatch durations of the same (counter-collecting) run, so that per-time ratios (clock = GRBM_GUI_ACTIVE / 8 / ns) can be formed
+    print("## dispatch durations in the PMC run (ns; serialised dispatches)")
+    q = ("select kernel_name, count(*), sum(duration), min(duration), max(duration) from "
+         "(select distinct dispatch_id, kernel_name, duration from counters_collection) group by kernel_name")
+    for k, n, s, lo, hi in cur.execute(q):
+        print(f"{k[:70]:70s} dispatches={n:5d} total_ns={s:14.0f} min_ns={lo:12.0f} max_ns={hi:12.0f}")
