@@ -195,6 +195,21 @@ int rt_hip_render_dev(const rt_scene* scene, const RtRayGenerator* gen, uint32_t
                       int32_t* d_first_id, float* d_first_t, uint32_t* d_seg_count, uint64_t* d_total_segments,
                       void* stream);
 
+/* Same as rt_hip_render_dev, but allocates nothing.  NO COUNTERPART IN THE REFERENCE (and none in its call sites): it exists
+ * for callers that cannot call hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation.  Its kernels are rt_hip_render_dev's; their scratch (work counter, streamed sphere table, continuing-ray
+ * rings, fixed-point framebuffer) lives in one static device array of 58,986,496 bytes (56.3 MiB) that every GPU the
+ * library is initialised on holds until the process ends.  Limits, beyond which the call fails with RT_ERR_UNSUPPORTED and
+ * a message naming the limit: cell_count <= 524,288 per call (split the cell range over several calls), at most 16,384
+ * scan-path spheres in the scene, at most 512 resident 512-thread blocks (256 CUs x 2).  It calls no hipMalloc / hipFree /
+ * allocating library routine and does not synchronise.  All calls on a GPU share that GPU's array, which keeps the last
+ * call's contents (the call clears what must start at zero on `stream`): two calls that overlap on one GPU race — issue
+ * them on one stream, or order them yourself.  It does not interact with the other entry points' scratch. */
+int rt_hip_render_dev_noalloc(const rt_scene* scene, const RtRayGenerator* gen, uint32_t spp, RtSettings settings,
+                              uint64_t seed, uint64_t cell_begin, uint64_t cell_count, uint64_t cell_step, float* d_fb,
+                              int32_t* d_first_id, float* d_first_t, uint32_t* d_seg_count, uint64_t* d_total_segments,
+                              void* stream);
+
 /* Number of objects / spheres / planes held by a scene (for harnesses and roofline accounting). */
 int rt_hip_scene_counts(const rt_scene* scene, uint64_t* n_objects, uint64_t* n_spheres, uint64_t* n_planes);
 

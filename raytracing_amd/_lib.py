@@ -25,6 +25,7 @@ EXPORTS = [
     "rt_hip_simulate_dev",
     "rt_hip_render",
     "rt_hip_render_dev",
+    "rt_hip_render_dev_noalloc",
     "rt_hip_set_scan_mode",
 ]
 
@@ -95,6 +96,8 @@ def lib():
     L.rt_hip_render_dev.argtypes = [vp, C.POINTER(abi.RtRayGenerator), u32, abi.RtSettings, u64, u64, u64, u64, vp, vp, vp,
                                     vp, vp, vp]
     L.rt_hip_render_dev.restype = C.c_int
+    L.rt_hip_render_dev_noalloc.argtypes = L.rt_hip_render_dev.argtypes
+    L.rt_hip_render_dev_noalloc.restype = C.c_int
     L.rt_hip_set_scan_mode.argtypes = [C.c_int]
     L.rt_hip_set_scan_mode.restype = C.c_int
     _LIB = L

@@ -34,6 +34,7 @@ struct Context {
     size_t prim_table_bytes = 0;
     // The scratch above is shared by every call on the context.  Calls are serialised on the host by g_mu; on the device a
     // call enqueued on another stream than its predecessor first waits for `last_done` (recorded behind every enqueue).
+    unsigned char* noalloc_scratch = nullptr;  // this device's copy of rt_scratch.hip's static array (hipGetSymbolAddress at init)
     hipEvent_t last_done = nullptr;
     hipStream_t last_stream = nullptr;
     bool last_valid = false;
@@ -228,13 +229,28 @@ Workspace context_workspace()
     return w;
 }
 
+Workspace fixed_workspace()
+{
+    unsigned char* base = g_ctx.noalloc_scratch;
+    Workspace w{};
+    w.fixed = true;
+    w.next_unit = reinterpret_cast<unsigned long long*>(base);
+    w.prim_table = reinterpret_cast<float4*>(base + rt::kNoAllocHeaderBytes);
+    w.prim_table_bytes = rt::kNoAllocTableBytes;
+    w.secq = reinterpret_cast<uint32_t*>(base + rt::kNoAllocHeaderBytes + rt::kNoAllocTableBytes);
+    w.secq_bytes = rt::kNoAllocRingBytes;
+    w.fb_q = reinterpret_cast<unsigned long long*>(base + rt::kNoAllocHeaderBytes + rt::kNoAllocTableBytes + rt::kNoAllocRingBytes);
+    w.fb_q_bytes = rt::kNoAllocFbBytes;
+    return w;
+}
+
 // Make sure a scratch buffer holds `need` bytes: grow the context's buffer, or refuse when the workspace is fixed.
 template <class T>
 int ensure_scratch(Workspace& w, T*& buf, size_t& have, T*& ctx_buf, size_t& ctx_have, size_t need, const char* what)
 {
     if (need <= have) return RT_OK;
     if (w.fixed)
-        return fail(RT_ERR_UNSUPPORTED, std::string(what) + " needs " + std::to_string(need) +
+        return fail(RT_ERR_UNSUPPORTED, std::string("rt_hip_render_dev_noalloc: ") + what + " needs " + std::to_string(need) +
                                             " bytes, the fixed workspace holds " + std::to_string(have));
     HIP_TRY(hipDeviceSynchronize());
     (void)hipFree(ctx_buf);
@@ -283,7 +299,7 @@ int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream,
     return RT_OK;
 }
 
-// rt_hip_render_dev: everything after the argument checks (g_mu held, device selected).
+// rt_hip_render_dev and rt_hip_render_dev_noalloc: everything after the argument checks (g_mu held, device selected).
 int render_enqueue(const rt_scene* scene, const RtRayGenerator* gen, uint32_t spp, RtSettings settings, uint64_t seed, uint64_t cell_begin,
                    uint64_t cell_count, uint64_t cell_step, float* d_fb, int32_t* d_first_id, float* d_first_t, uint32_t* d_seg_count,
                    uint64_t* d_total_segments, hipStream_t hs, Workspace& ws)
@@ -345,6 +361,10 @@ int rt_hip_init(int device_ordinal)
     if (!g_ctx.ready) {
         HIP_TRY(hipMalloc((void**)&g_ctx.counters, kCounterRing * sizeof(unsigned long long)));
         HIP_TRY(hipEventCreateWithFlags(&g_ctx.last_done, hipEventDisableTiming));
+        // this device's copy of the no-alloc workspace (rt_scratch.hip); device_ordinal is current
+        void* scratch = nullptr;
+        HIP_TRY(rt::noalloc_scratch_address(&scratch));
+        g_ctx.noalloc_scratch = static_cast<unsigned char*>(scratch);
         g_ctx.device = device_ordinal;
         g_ctx.n_cu = prop.multiProcessorCount;
         g_ctx.ready = true;
@@ -654,6 +674,30 @@ int rt_hip_render_dev(const rt_scene* scene, const RtRayGenerator* gen, uint32_t
                                 d_total_segments, hs, ws))
         return rc;
     return mark_enqueued(hs);
+}
+
+int rt_hip_render_dev_noalloc(const rt_scene* scene, const RtRayGenerator* gen, uint32_t spp, RtSettings settings, uint64_t seed,
+                              uint64_t cell_begin, uint64_t cell_count, uint64_t cell_step, float* d_fb, int32_t* d_first_id,
+                              float* d_first_t, uint32_t* d_seg_count, uint64_t* d_total_segments, void* stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = check_common(scene, settings)) return rc;
+    if (!d_fb) return fail(RT_ERR_INVALID, "gen / fb must not be null");
+    if (int rc = check_render_args(gen, spp, cell_begin, cell_count, cell_step)) return rc;
+    if (cell_count == 0) return RT_OK;
+    if (settings.max_bounces == 0) return fail(RT_ERR_INVALID, "max_bounces == 0 is handled by the host entry point only");
+    if (cell_count > rt::kNoAllocMaxCells)
+        return fail(RT_ERR_UNSUPPORTED, "rt_hip_render_dev_noalloc: cell_count " + std::to_string(cell_count) + " exceeds the fixed workspace's limit of " +
+                                            std::to_string(rt::kNoAllocMaxCells) + " cells per call (split the cell range)");
+    if (scene->dev.n_sph > rt::kNoAllocMaxSpheres)
+        return fail(RT_ERR_UNSUPPORTED, "rt_hip_render_dev_noalloc: the scene's " + std::to_string(scene->dev.n_sph) + " scan-path spheres exceed the fixed workspace's limit of " +
+                                            std::to_string(rt::kNoAllocMaxSpheres));
+    // No hipMalloc / hipFree below this line: the workspace is the static device array resolved at rt_hip_init.  It is shared
+    // by every call of this entry point on the device and keeps the last call's contents; what must start at zero (work
+    // counter, fixed-point sums) is cleared on `stream` first.  Calls that overlap on one GPU race: the caller orders them.
+    Workspace ws = fixed_workspace();
+    return render_enqueue(scene, gen, spp, settings, seed, cell_begin, cell_count, cell_step, d_fb, d_first_id, d_first_t, d_seg_count,
+                          d_total_segments, (hipStream_t)stream, ws);
 }
 
 int rt_hip_render(const rt_scene* scene, const RtRayGenerator* gen, uint32_t spp, RtSettings settings, uint64_t seed,

@@ -114,6 +114,17 @@ struct TraceParams {
 constexpr unsigned kSecCap = 256;    // entries per wave ring (a primary step adds <= 128 to a residue < 128)
 constexpr unsigned kSecFields = 10;  // o.xyz d.xyz ior cell sample bounce
 
+// ---- fixed workspace of rt_hip_render_dev_noalloc (rt_scratch.hip): one static device array, carved into regions ----
+constexpr size_t kNoAllocMaxCells = 1u << 19;       // cells per call: 32 B of accumulators each
+constexpr size_t kNoAllocMaxSpheres = 1u << 14;     // scan-path spheres (streamed shared-origin table, 16 B each)
+constexpr size_t kNoAllocHeaderBytes = 4096;        // work counter (8 B used)
+constexpr size_t kNoAllocTableBytes = kNoAllocMaxSpheres * sizeof(float4);
+constexpr size_t kNoAllocRingBytes = (size_t)512 * 8 * kSecFields * kSecCap * sizeof(uint32_t);  // 512 resident blocks x 8 waves (256 CUs x 2)
+constexpr size_t kNoAllocFbBytes = kNoAllocMaxCells * 4 * sizeof(unsigned long long);
+constexpr size_t kNoAllocScratchBytes = kNoAllocHeaderBytes + kNoAllocTableBytes + kNoAllocRingBytes + kNoAllocFbBytes;  // 58,986,496 B (56.3 MiB)
+static_assert(kNoAllocHeaderBytes % 256 == 0 && kNoAllocTableBytes % 256 == 0 && kNoAllocRingBytes % 256 == 0, "regions stay 256-byte aligned");
+// Device address of the calling thread's current device's copy of the array (hipGetSymbolAddress; no allocation).
+hipError_t noalloc_scratch_address(void** out);
 
 // Launches the trace kernel on `stream` of `device` (the current device; per-device launch state is keyed by it).
 hipError_t launch_trace(const TraceParams& p, int n_cu, int device, hipStream_t stream);

@@ -178,6 +178,13 @@ class Scene:
                                       d_fb, d_first_id, d_first_t, d_seg_count, d_total, stream))
 
 
+    def render_dev_noalloc(self, gen, spp, setting, seed, cell_begin, cell_count, cell_step, d_fb, d_first_id, d_first_t, d_seg_count,
+                           d_total, stream):
+        """rt_hip_render_dev_noalloc: same call on the library's fixed device workspace — no hipMalloc (include/rt_hip.h for the limits)."""
+        check(lib().rt_hip_render_dev_noalloc(self._h, C.byref(gen), spp, setting.as_c(), seed, cell_begin, cell_count, cell_step,
+                                              d_fb, d_first_id, d_first_t, d_seg_count, d_total, stream))
+
+
 def projector(origin, target_corner, target_u, target_v, count_u, count_v, current_ior=1.0):
     """RayGeneratorConfig::Projector (object_generator_config.rs:23-31)."""
     g = abi.RtRayGenerator()

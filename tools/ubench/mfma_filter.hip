@@ -221,7 +221,10 @@ __global__ __launch_bounds__(512, 4) void rate_kernel(float* out, const uint16_t
             keep += 1.f;
             hits = 0;
         }
-        b0[1] = (short)it;  // operands change every iteration
+        b0[1] = (short)it;  // every operand changes every iteration (nothing is loop-invariant)
+        b1[2] = (short)(it + 1);
+        b2[3] = (short)(it + 2);
+        b3[4] = (short)(it + 3);
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (blockIdx.x == 0 && threadIdx.x == 0) { stamps[0] = t1 - t0; stamps[1] = r1 - r0; }
