@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py — Mrays/s of the ray-path hot loop on the C2 workload (BASELINE.json configs[1]).
+"""bench.py — Mrays/s of the ray-path hot loop (BASELINE.json metric).
 
-A step = one pass of the hot path over one frame of synthetic input: 1,000 spheres, Projector 1920x1080 cells,
-64 paths per cell, max_bounces 8.  A "ray" = one bounce-loop iteration (scene.rs:49), counted by
-the kernel.  N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders the same frame for
-its own sample block (weak scaling) and the framebuffers are summed to rank 0 over RCCL inside the timed region.
+A step = one pass of the hot path over one frame of synthetic input.  A "ray" = one bounce-loop iteration
+(scene.rs:49), counted by the kernel.
+
+  --gpus 1 (default)  workload C2 = BASELINE.json configs[1], the configuration the metric is quoted on: 1,000 spheres,
+                      Projector 1920x1080 cells, 64 paths per cell, max_bounces 8, one launch per frame.
+  --gpus N > 1        (launched by torch.distributed.run, one rank per GPU) workload C4 = configs[3]: 10,000 spheres,
+                      3840x2160 cells, 1,024 spp, the frame's cells dealt round-robin over the ranks
+                      (sharding.cell_shard), ONE all_gather_into_tensor over RCCL per frame inside the timed region, fixed
+                      total work ("scaling": "strong").  Rank 0 checks the gathered image against the stored single-GPU
+                      checksum (tests/golden/frame_checksums.json) after the timed region.
+  --workload c2|c4    overrides the choice (e.g. `--gpus 1 --workload c4` = the single-GPU reference of the scaling curve).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -19,11 +25,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_TEST = 17  # algorithmic reject-path cost of one ray-sphere test (sphere.rs:13-17)
-PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (packed FMA)
+PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (packed FMA) at 2.4 GHz
+# FMA instructions the filter EXECUTES per ray-sphere test: primary (shared-origin) rays 2, continuing rays 7
+FMA_PER_PRIMARY_TEST, FMA_PER_CONTINUING_TEST = 2, 7
+CHECKSUMS = os.path.join(ROOT, "tests", "golden", "frame_checksums.json")
+PMC = os.path.join(ROOT, "profiles", "pmc_constants.json")
 
 
-def cpu_baseline(cfg, n_spheres):
-    """Oracle (C++ restatement, kind 'port') on the host cores, on a bounded sample of the same workload."""
+def cpu_baseline(n_spheres):
+    """Oracle (C++ restatement, kind 'port') on the host cores, on a bounded sample of the C2 workload."""
     from oracle import binding as ob
     from raytracing_amd import synth
 
@@ -48,25 +58,31 @@ def cpu_baseline(cfg, n_spheres):
     }
 
 
+def checksum_key(name, w, h, spp, seed, depth):
+    return f"{name}:{w}x{h}:spp{spp}:seed{seed}:depth{depth}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--workload", choices=["auto", "c2", "c4"], default="auto")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--print-checksum", action="store_true", help="also print the frame checksum key and value (to store it)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
-    from raytracing_amd import engine, synth
+    from raytracing_amd import engine, sharding, synth
     from raytracing_amd.engine import SimulationSettingsConfig
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # RT_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, reduce) even with one rank, to rehearse it on a 1-GPU box
+    # RT_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, all-gather) even with one rank, to rehearse it on a 1-GPU box
     use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -86,108 +102,129 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-
-    def reduce_fb(t):
-        """Sum the ranks' framebuffers to rank 0.  Over RCCL the reduce is asynchronous (RCCL's own stream, ordered after the
-        render that filled `t`), so it overlaps the next frame's render into the other buffer; returns the work handle."""
-        if rehearsal:
-            h = t.cpu()
-            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
-            return None
-        return dist.reduce(t, dst=0, op=dist.ReduceOp.SUM, async_op=True)
-
-    def allreduce_scalar(t, op):
-        if rehearsal:
-            h = t.cpu()
-            dist.all_reduce(h, op=op)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, op=op)
+    dev = torch.device("cuda", local_rank if (world > 1 and not rehearsal) else 0)
     engine.init(dev.index)
 
-    cfg = synth.config_c2(args.width, args.height)
-    cfg["spp"] = args.spp
+    name = args.workload if args.workload != "auto" else ("c2" if world == 1 else "c4")
+    make = synth.config_c2 if name == "c2" else synth.config_c4
+    w = args.width or (1920 if name == "c2" else 3840)
+    h = args.height or (1080 if name == "c2" else 2160)
+    cfg = make(w, h)
+    spp = args.spp or cfg["spp"]
     scene = engine.Scene(cfg["objects"])
     n_obj, n_sph, n_pl = scene.counts()
     st = SimulationSettingsConfig(cfg["infinity_distance"], cfg["max_bounces"])
-    n_cells = args.width * args.height
-    # inputs (scene, generator constants) and outputs resident in HBM before the timed region
-    fbs = [torch.empty((n_cells, 3), dtype=torch.float32, device=dev) for _ in range(2 if use_dist else 1)]  # double-buffered for the reduce
-    pending = [None, None]
-    first_id = torch.empty(n_cells, dtype=torch.int32, device=dev)
-    first_t = torch.empty(n_cells, dtype=torch.float32, device=dev)
-    seg = torch.empty(n_cells, dtype=torch.int32, device=dev)
-    total = torch.zeros(1, dtype=torch.int64, device=dev)
-    seed = (cfg["seed"] + rank * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF  # rank = sample block
+    n_cells = w * h
 
-    frame = [0]
+    class GlooDist:  # rehearsal: the all-gather runs over gloo on host copies of the shards
+        @staticmethod
+        def all_gather_into_tensor(out, inp):
+            ho = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(ho, inp.cpu())
+            out.copy_(ho)
 
-    def step(events=None):
-        b = frame[0] % len(fbs)
-        frame[0] += 1
-        if pending[b] is not None:  # the reduce that last read this buffer must be done before it is overwritten
-            pending[b].wait()
-            pending[b] = None
-        fb = fbs[b]
-        if events:
-            events[0].record()
-        stream = torch.cuda.current_stream().cuda_stream
-        scene.render_dev(cfg["gen"], cfg["spp"], st, seed, 0, n_cells, 1, fb.data_ptr(), first_id.data_ptr(), first_t.data_ptr(),
-                         seg.data_ptr(), total.data_ptr(), stream)
-        if events:
-            events[1].record()
-        if use_dist:
-            pending[b] = reduce_fb(fb)
+    def render_cells(begin, count, step, fb_rows, total_slot):
+        scene.render_dev(cfg["gen"], spp, st, cfg["seed"], begin, count, step, fb_rows.data_ptr(), 0, 0, 0, total_slot.data_ptr(),
+                         torch.cuda.current_stream().cuda_stream)
+
+    # inputs (scene, generator constants) and outputs resident in HBM before the timed region; C2's 2,073,600 cells are one launch
+    frame = sharding.ShardedFrame(render_cells, n_cells, rank, world, GlooDist if rehearsal else dist, dev, max_cells_per_launch=1 << 21)
 
     def barrier():
-        for b in range(len(pending)):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # bring the GPU to its steady clocks before anything is counted (a cold first frame runs ~8 % slower); untimed, like the W warmup steps
-    # (render only, no collective: the number of pre-warm frames is time-based and may differ between ranks)
+    # bring the GPU to its steady clocks before anything is counted (a cold first frame runs ~8 % slower); untimed, like the W
+    # warmup steps (render only, no collective: the number of pre-warm frames is time-based and may differ between ranks)
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < 0.5:
-        scene.render_dev(cfg["gen"], cfg["spp"], st, seed, 0, n_cells, 1, fbs[0].data_ptr(), first_id.data_ptr(), first_t.data_ptr(),
-                         seg.data_ptr(), total.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        frame.render()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
-        step()
+        frame.step()
     barrier()
-    # kernel duration: HIP events on the launch stream around each render_dev (no collective inside the pair)
+    # kernel duration: HIP events on the launch stream around each frame's launches (the collective is outside the pair)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    segs_done = 0
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(ev[k])
+        ev[k][0].record()
+        frame.render()
+        ev[k][1].record()
+        frame.gather()
     barrier()
     elapsed = time.perf_counter() - t0
-    segs_per_step = int(total.item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    segs_local = frame.segments()
+    render_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    s = torch.tensor([segs_per_step], dtype=torch.int64, device=dev)
+    s = torch.tensor([segs_local], dtype=torch.int64, device=dev)
     if use_dist:
-        allreduce_scalar(t, dist.ReduceOp.MAX)
-        allreduce_scalar(s, dist.ReduceOp.SUM)
-    elapsed_max = float(t.item())
-    segs_all = int(s.item())
+        for x, op in ((t, dist.ReduceOp.MAX), (s, dist.ReduceOp.SUM)):
+            if rehearsal:
+                hx = x.cpu()
+                dist.all_reduce(hx, op=op)
+                x.copy_(hx)
+            else:
+                dist.all_reduce(x, op=op)
+    elapsed_max, segs_all = float(t.item()), int(s.item())
 
     if rank == 0:
+        # the assembled image against the stored single-GPU checksum (integer checksum: independent of the rank count)
+        key = checksum_key(name, w, h, spp, cfg["seed"], cfg["max_bounces"])
+        got = sharding.frame_checksum(frame.image())
+        stored = json.load(open(CHECKSUMS)) if os.path.exists(CHECKSUMS) else {}
+        if key in stored:
+            if int(stored[key], 16) != got:
+                raise SystemExit(f"bench.py: frame checksum {got:#018x} differs from the stored single-GPU value {stored[key]} for {key}")
+            image_check = f"gathered image == stored single-GPU checksum {stored[key]}"
+        else:
+            image_check = f"no stored checksum for {key} (computed {got:#018x})"
+        if args.print_checksum:
+            print(f"checksum {key} {got:#018x}", file=sys.stderr, flush=True)
+
         value = segs_all * args.steps / elapsed_max / 1e6
-        achieved = segs_per_step * FLOP_PER_TEST * n_sph / (kernel_ms * 1e-3) / 1e12
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
+        launches = len(frame.launches)
+        kernel_ms = render_ms / launches  # average duration of one launch of the dominant kernel (finalize + memsets: < 0.5 %)
+        prim_local = frame.count * spp  # primary segments of this rank's cells; the rest are continuing rays
+        cont_local = segs_local - prim_local
+        n_pad = (n_sph + 3) // 4 * 4 if n_sph <= 1024 else (n_sph + 63) // 64 * 64
+        fma_flop = 2.0 * n_pad * (FMA_PER_PRIMARY_TEST * prim_local + FMA_PER_CONTINUING_TEST * cont_local)
+        achieved = fma_flop / (render_ms * 1e-3) / 1e12
+        algorithmic = segs_local * FLOP_PER_TEST * n_sph / (render_ms * 1e-3) / 1e12
+        pmc = {}
+        if os.path.exists(PMC):
             try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                pmc = json.load(open(PMC)).get(name, {})
             except Exception:
-                traffic = None
+                pmc = {}
+        traffic = pmc.get("hbm_bytes_per_launch")
+        clk = pmc.get("clock_ghz")
+        roof = {
+            "bound": "valu_fp32",
+            "kernel": "pinhole_kernel<2, %s, false> (Projector render loop)" % ("false" if n_sph <= 1024 else "true"),
+            "achieved": achieved,
+            "peak": PEAK_FP32_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_TFLOPS,
+            "traffic": traffic,
+            "kernel_ms": kernel_ms,
+            "launches_per_step": launches,
+            "definition": "EXECUTED filter work: 2 FLOP x (2 FMA per primary test + 7 FMA per continuing-ray test) x padded spheres x segments "
+                          "of this rank / its kernel time (HIP events on the launch stream), over the packed-FMA FP32 vector peak; compares, "
+                          "v_max3, LDS broadcasts and the exact confirm stage are not counted as FLOP",
+            "frac_at_sustained_clock": None if not clk else achieved / (PEAK_FP32_TFLOPS * clk / 2.4),
+            "sustained_clock_ghz": clk,
+            "valu_issue_util": pmc.get("valu_issue_util"),
+            "valu_lane_util": pmc.get("valu_lane_util"),
+            "pmc_source": pmc.get("source"),
+            "algorithmic_equiv": {"flop_per_test": FLOP_PER_TEST, "achieved": algorithmic, "frac": algorithmic / PEAK_FP32_TFLOPS,
+                                  "note": "SURVEY.md §8d accounting (17 FLOP per test the reference's formulation would spend); can exceed 1 because "
+                                          "the filter executes fewer operations than that formulation"},
+            "hbm": None if traffic is None else {"achieved": traffic / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                                  "frac": traffic / (kernel_ms * 1e-3) / 1e9 / 8000.0},
+        }
+        full = "C2" if name == "c2" else "C4"
         out = {
             "metric": "Mrays/sec (primary+bounce) at 1080p 64spp, 1/8 GPU; % of FP32 VALU peak",
             "value": value,
@@ -197,38 +234,25 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"C2: {n_sph} spheres (seed 0xC0FFEE), Projector {args.width}x{args.height} cells, {cfg['spp']} spp, "
-                            f"max_bounces {cfg['max_bounces']}; one frame per GPU per step",
-                "segments_per_step_per_gpu": segs_per_step,
-                "sharding": "one sample block (frame) per rank; framebuffer reduce to rank 0 over RCCL, overlapped with the next frame" if world > 1 else "single GPU",
+                "workload": f"{full}: {n_sph} spheres (seed 0xC0FFEE), Projector {w}x{h} cells, {spp} spp, max_bounces {cfg['max_bounces']}; "
+                            f"one frame per step" + ("" if world == 1 else f", cells dealt round-robin over {world} GPUs, one all-gather per frame"),
+                "segments_per_step": segs_all,
+                "sharding": "single GPU" if world == 1 else "cell = rank + m * world (sharding.cell_shard); framebuffer shards all-gathered over RCCL inside the timed region",
+                "image_check": image_check,
                 # "1/8 GPU" read both ways: value is per whole MI355X (one of a node's eight) at N=1; one XCD's share is value/8/N
                 "mrays_per_s_per_gpu": value / world,
                 "mrays_per_s_per_xcd": value / world / 8,
                 "pct_of_fp32_valu_peak": 100.0 * achieved / PEAK_FP32_TFLOPS,
             },
-            "roofline": {
-                "bound": "valu_fp32",
-                "kernel": "pinhole_kernel (Projector render loop; general trace_kernel for other generators)",
-                "achieved": achieved,
-                "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_TFLOPS,
-                "traffic": traffic,
-                "kernel_ms": kernel_ms,
-                "flop_per_segment": FLOP_PER_TEST * n_sph,
-                "note": "algorithmic 17 FLOP per ray-sphere test x spheres x segments / kernel time (HIP events on the launch stream); "
-                        "the path is FP32-VALU-bound (no MFMA by design), HBM shown for completeness",
-                "hbm": None if traffic is None else {"achieved": traffic / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                                      "frac": traffic / (kernel_ms * 1e-3) / 1e9 / 8000.0},
-            },
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, n_sph)
+        if world == 1 and name == "c2" and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n_sph)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

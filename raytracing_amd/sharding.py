@@ -46,6 +46,60 @@ def gather_image(local, rank, world, n_cells, dist, dst=None):
     return interleave_shards(out.reshape((world, cap) + tuple(local.shape[1:])), n_cells)
 
 
+def frame_checksum(fb):
+    """Order-independent, position-sensitive 64-bit checksum of an [n, 3] float32 image (torch tensor, any device):
+    sum over elements of (bit pattern * (2654435761 * index + 1)) mod 2^64.  Integer arithmetic, so the value does not
+    depend on how the image was computed, sharded or summed — equal images give equal checksums on any rank count."""
+    import torch
+
+    bits = fb.contiguous().view(torch.int32).reshape(-1).to(torch.int64) & 0xFFFFFFFF
+    idx = torch.arange(bits.numel(), dtype=torch.int64, device=bits.device)
+    return int((bits * (idx * 2654435761 + 1)).sum().item()) & 0xFFFFFFFFFFFFFFFF  # int64 products / sums wrap mod 2^64
+
+
+class ShardedFrame:
+    """One frame of the generator-driven loop tile-sharded over `world` ranks (BASELINE.json configs[3]).
+
+    `render_cells(cell_begin, cell_count, cell_step, fb_rows, total_slot)` enqueues the render of those generator cells into
+    the [cell_count, 3] float32 tensor `fb_rows` and their segment count into the 1-element int64 tensor `total_slot`
+    (on the GPU: engine.Scene.render_dev on the current stream; the CPU tests pass an oracle-backed stand-in).  `step()`
+    renders this rank's cells rank, rank + world, ... in launches of at most `max_cells_per_launch` cells and then does the
+    frame's ONE exchange, an all-gather of the equal-sized shards; nothing in it synchronises with the host."""
+
+    def __init__(self, render_cells, n_cells, rank, world, dist, device, max_cells_per_launch=1 << 19):
+        import torch
+
+        self.render_cells, self.n_cells, self.rank, self.world, self.dist = render_cells, n_cells, rank, world, dist
+        self.begin, self.count, self.step_cells = cell_shard(rank, world, n_cells)
+        self.cap = shard_capacity(world, n_cells)
+        self.launches = [(done, min(max_cells_per_launch, self.count - done)) for done in range(0, self.count, max_cells_per_launch)]
+        self.local = torch.zeros((self.cap, 3), dtype=torch.float32, device=device)  # rows past `count` stay zero (padding)
+        self.totals = torch.zeros(max(1, len(self.launches)), dtype=torch.int64, device=device)
+        self.gathered = torch.empty((world * self.cap, 3), dtype=torch.float32, device=device) if world > 1 else None
+
+    def render(self):
+        for k, (done, n) in enumerate(self.launches):
+            self.render_cells(self.begin + done * self.step_cells, n, self.step_cells, self.local[done:done + n], self.totals[k:k + 1])
+
+    def gather(self):
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(self.gathered, self.local)
+
+    def step(self):
+        self.render()
+        self.gather()
+
+    def image(self):
+        """[n_cells, 3] in cell order (a view of the gathered shards)."""
+        if self.world == 1:
+            return self.local[: self.n_cells]
+        return interleave_shards(self.gathered.reshape(self.world, self.cap, 3), self.n_cells)
+
+    def segments(self):
+        """This rank's ray-segment count of the last frame (synchronises)."""
+        return int(self.totals.sum().item())
+
+
 def render_sharded(scene, gen, spp, setting, seed, rank, world, dist, device, max_cells_per_launch=1 << 19):
     """One frame over `world` GPUs: this rank renders cells rank, rank+world, ... (in launches of at most
     `max_cells_per_launch` cells), then one all-gather assembles the image on every rank.
@@ -53,20 +107,17 @@ def render_sharded(scene, gen, spp, setting, seed, rank, world, dist, device, ma
     import torch
 
     n_cells = gen.count_u * gen.count_v
-    begin, count, step = cell_shard(rank, world, n_cells)
-    cap = shard_capacity(world, n_cells)
-    fb = torch.zeros((cap, 3), dtype=torch.float32, device=device)
-    total = torch.zeros(1, dtype=torch.int64, device=device)
     stream = torch.cuda.current_stream(device).cuda_stream
-    segments, done = 0, 0
-    while done < count:
-        n = min(max_cells_per_launch, count - done)
-        scene.render_dev(gen, spp, setting, seed, begin + done * step, n, step, fb[done:].data_ptr(), 0, 0, 0, total.data_ptr(), stream)
-        segments += int(total.item())  # also orders the launches: the library's scratch is shared between calls
-        done += n
-    if world > 1:
-        return gather_image(fb, rank, world, n_cells, dist), segments
-    return fb[:n_cells], segments
+
+    def render_cells(begin, count, step, fb_rows, total_slot):
+        scene.render_dev(gen, spp, setting, seed, begin, count, step, fb_rows.data_ptr(), 0, 0, 0, total_slot.data_ptr(), stream)
+
+    frame = ShardedFrame(render_cells, n_cells, rank, world, dist, device, max_cells_per_launch)
+    frame.render()
+    if world > 1 and hasattr(dist, "all_gather_into_tensor"):
+        frame.gather()
+        return frame.image(), frame.segments()
+    return gather_image(frame.local, rank, world, n_cells, dist) if world > 1 else frame.local[:n_cells], frame.segments()
 
 
 def main(argv=None):

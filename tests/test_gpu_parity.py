@@ -798,3 +798,37 @@ def test_calls_from_another_host_thread_and_stream(engine):
     for seed in (1, 2):
         fb, seg, tot = results[seed]
         assert np.array_equal(fb, want[seed][0]) and np.array_equal(seg.astype(np.uint32), want[seed][3]) and tot == want[seed][4]
+
+
+def test_bench_sharded_path_and_stored_checksums(engine):
+    """bench.py's frame step (sharding.ShardedFrame on rt_hip_render_dev) as ranks of a 3-GPU job would run it, assembled as
+    the all-gather would, and the single-rank run, against the oracle-made checksums in tests/golden/frame_checksums.json."""
+    import json
+
+    import torch
+
+    from raytracing_amd import sharding
+
+    stored = json.load(open(os.path.join(GOLD, "frame_checksums.json")))
+    dev = torch.device("cuda", 0)
+    for name, w, h, spp in [("c2", 96, 54, 4), ("c4", 24, 16, 2)]:
+        cfg = (synth.config_c2 if name == "c2" else synth.config_c4)(w, h)
+        sc = engine.Scene(cfg["objects"])
+        st = SimulationSettingsConfig(cfg["infinity_distance"], cfg["max_bounces"])
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def render_cells(begin, count, step, fb_rows, total_slot):
+            sc.render_dev(cfg["gen"], spp, st, cfg["seed"], begin, count, step, fb_rows.data_ptr(), 0, 0, 0, total_slot.data_ptr(), stream)
+
+        key = f"{name}:{w}x{h}:spp{spp}:seed{cfg['seed']}:depth{cfg['max_bounces']}"
+        one = sharding.ShardedFrame(render_cells, w * h, 0, 1, None, dev, max_cells_per_launch=1000)
+        one.step()
+        assert sharding.frame_checksum(one.image()) == int(stored[key], 16)
+        shards, segs = [], 0
+        for rank in range(3):
+            f = sharding.ShardedFrame(render_cells, w * h, rank, 3, None, dev, max_cells_per_launch=700)
+            f.render()
+            shards.append(f.local.clone())
+            segs += f.segments()
+        img = sharding.interleave_shards(torch.stack(shards), w * h)
+        assert sharding.frame_checksum(img) == int(stored[key], 16) and segs == one.segments()

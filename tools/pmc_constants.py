@@ -1,0 +1,59 @@
+"""Derives the PMC constants bench.py reports (roofline.traffic, valu_issue_util, valu_lane_util, sustained clock) from a
+committed rocprofv3 summary (tools/rocpd_summary.py text) and merges them into profiles/pmc_constants.json.
+
+usage: python tools/pmc_constants.py NAME SUMMARY.txt [KERNEL_SUBSTRING]
+  valu_issue_util = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * SQ_BUSY_CYCLES / 32 SEs)      (quad-cycles -> cycles; busy cycles per SE)
+  valu_lane_util  = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
+  clock_ghz       = SQ_BUSY_CYCLES / 32 / (kernel time of the same pass)                  (cross-check: GRBM_GUI_ACTIVE / 8 / time)
+  hbm_bytes_per_launch = WRITE_SIZE KB * 1024 + 2 * FETCH_SIZE KB * 1024 per dispatch     (gfx950: FETCH_SIZE reports half the bytes,
+                                                                                           MI355X_MICROARCH.md §HBM)
+"""
+import json
+import os
+import re
+import sys
+
+name, path = sys.argv[1], sys.argv[2]
+kernel = sys.argv[3] if len(sys.argv) > 3 else "pinhole_kernel"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+counters, disp, passes = {}, {}, []
+cur = None
+for line in open(path):
+    if line.startswith("# source:"):
+        cur = {"counters": {}, "ns": None, "n": None}
+        passes.append(cur)
+        continue
+    if kernel not in line or cur is None:
+        continue
+    m = re.search(r"\s([A-Z][A-Za-z0-9_]+)\s+(\d+)\s+dispatches=(\d+)\s*$", line)
+    if m:
+        cur["counters"][m.group(1)] = (float(m.group(2)), int(m.group(3)))
+        continue
+    m = re.search(r"dispatches=\s*(\d+)\s+total_ns=\s*(\d+)", line)
+    if m:
+        cur["n"], cur["ns"] = int(m.group(1)), float(m.group(2))
+out = {"source": os.path.relpath(path, ROOT), "kernel": kernel}
+for p in passes:
+    c = p["counters"]
+    if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c and p["ns"]:
+        busy_cycles = c["SQ_BUSY_CYCLES"][0] / 32.0
+        out["valu_issue_util"] = c["SQ_ACTIVE_INST_VALU"][0] * 4.0 / (1024.0 * busy_cycles)
+        out["clock_ghz"] = busy_cycles / p["ns"]
+        out["valu_insts_per_launch"] = c["SQ_INSTS_VALU"][0] / c["SQ_INSTS_VALU"][1] if "SQ_INSTS_VALU" in c else None
+        if "SQ_THREAD_CYCLES_VALU" in c:
+            out["valu_lane_util"] = c["SQ_THREAD_CYCLES_VALU"][0] / (64.0 * c["SQ_ACTIVE_INST_VALU"][0])
+    if "GRBM_GUI_ACTIVE" in c and p["ns"]:
+        out["clock_ghz_grbm"] = c["GRBM_GUI_ACTIVE"][0] / 8.0 / p["ns"]
+    if "WRITE_SIZE" in c:
+        out["write_bytes_per_launch"] = c["WRITE_SIZE"][0] * 1024.0 / c["WRITE_SIZE"][1]
+    if "FETCH_SIZE" in c:
+        out["fetch_bytes_per_launch"] = 2.0 * c["FETCH_SIZE"][0] * 1024.0 / c["FETCH_SIZE"][1]
+    if "TCC_EA0_ATOMIC_sum" in c:
+        out["atomic_requests_per_launch"] = c["TCC_EA0_ATOMIC_sum"][0] / c["TCC_EA0_ATOMIC_sum"][1]
+if "write_bytes_per_launch" in out and "fetch_bytes_per_launch" in out:
+    out["hbm_bytes_per_launch"] = out["write_bytes_per_launch"] + out["fetch_bytes_per_launch"]
+dst = os.path.join(ROOT, "profiles", "pmc_constants.json")
+allc = json.load(open(dst)) if os.path.exists(dst) else {}
+allc[name] = out
+json.dump(allc, open(dst, "w"), indent=1, sort_keys=True)
+print(json.dumps(out, indent=1))
