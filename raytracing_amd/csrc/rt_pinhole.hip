@@ -308,17 +308,7 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 }
             }
             // per-cell sums: neighbouring lanes of one cell are combined first (rt_device.h flush_cells)
-#ifdef RT_AB_SIMPLE_FLUSH  // A/B build only (tools/r02_profile_b.sh): one atomic per lane and word, as in round 1
-            if (fl) {
-                unsigned long long* q = p.fb_q + (uint64_t)fcell * 4;
-                if (fx) atomicAdd(q + 0, fx);
-                if (fy) atomicAdd(q + 1, fy);
-                if (fz) atomicAdd(q + 2, fz);
-                atomicAdd(q + 3, fsegs);
-            }
-#else
             flush_cells(p.fb_q, fl, fcell, fx, fy, fz, fsegs, reinterpret_cast<uint32_t*>(&w.stash[0][0]), lane);
-#endif
             // append continuing rays to the ring (wave-uniform control flow)
             const unsigned long long pm = __ballot(push);
             if (pm) {

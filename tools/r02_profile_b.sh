@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/r02_profile_b.sh TAG
-# A/B of the per-cell flush on one box (librt_hip_ab.so = -DRT_AB_SIMPLE_FLUSH: one atomic per lane and word), then the
+# A/B of the per-cell flush on one box (librt_hip_ab.so = a build with one atomic per lane and word in place of flush_cells, made by hand for this measurement), then the
 # full profile of the shipped build (tools/profile_bench.sh: bench line, kernel trace, SQ / FETCH_SIZE / WRITE_SIZE passes)
 # and the WRITE_SIZE pass of the A/B build.
 set -e
