@@ -432,7 +432,7 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     if (n_objects >= (1ull << 23)) return fail(RT_ERR_INVALID, "too many objects (limit 2^23)");
     *out_scene = nullptr;
 
-    std::vector<float4> sph_cull, sph_exact, pl_pos, pl_nrm, obj_geom(n_objects), obj_aux(n_objects);
+    std::vector<float4> sph_cull, sph_exact, sph_box, pl_pos, pl_nrm, obj_geom(n_objects), obj_aux(n_objects);
     std::vector<int32_t> sph_obj, pl_obj;
     std::vector<uint2> obj_mat(n_objects);
     std::vector<uint32_t> obj_shape(n_objects);
@@ -448,9 +448,11 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
         obj_mat[k] = make_uint2(o.material_kind, pbits);
         obj_shape[k] = o.shape;
         const float px = o.position[0], py = o.position[1], pz = o.position[2];
-        // Spheres and planes with rotation 0 fold their Transform exactly and ride the scan path;
-        // every other object is evaluated per lane with the reference's intersect_all (rt_complex.h).
-        const bool fast = (o.shape == RT_SHAPE_SPHERE || o.shape == RT_SHAPE_PLANE) && o.rotation_y_deg == 0.0f;
+        // Spheres, planes and boxes with rotation 0 fold their Transform exactly and ride the scan path (a box
+        // behind its bounding sphere); every other object is evaluated per lane with the reference's intersect_all (rt_complex.h).
+        const bool finite_box = o.shape == RT_SHAPE_BOX && std::isfinite(o.shape_param[0]) && std::isfinite(o.shape_param[1]) &&
+                                std::isfinite(o.shape_param[2]);
+        const bool fast = (o.shape == RT_SHAPE_SPHERE || o.shape == RT_SHAPE_PLANE || finite_box) && o.rotation_y_deg == 0.0f;
         if (!fast) {
             rt::host::Program pr;
             std::string err;
@@ -488,10 +490,26 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
             const double rr = (double)r * r;
             sph_cull.push_back(make_float4(px, py, pz, (float)(pp - rr)));
             sph_exact.push_back(make_float4(px, py, pz, r));
+            sph_box.push_back(make_float4(0, 0, 0, 0));
             sph_obj.push_back((int32_t)k);
             obj_geom[k] = make_float4(px, py, pz, r);
             obj_aux[k] = make_float4(0, 0, 0, 0);
             if (pp + rr > c2max) c2max = pp + rr;
+        } else if (o.shape == RT_SHAPE_BOX) {
+            // shape_config.rs:61-68: AxisAlignedBox(-size/2, size/2).  The filter sees the box's bounding sphere (rounded up); the
+            // confirm stage runs the exact slab test.
+            const float hx = o.shape_param[0] / 2.0f, hy = o.shape_param[1] / 2.0f, hz = o.shape_param[2] / 2.0f;
+            const double rr = ((double)hx * hx + (double)hy * hy + (double)hz * hz) * (1.0 + 1e-6) + 1e-30;
+            const double pp = (double)px * px + (double)py * py + (double)pz * pz;
+            float rb = (float)std::sqrt(rr);
+            if ((double)rb * rb < rr) rb = std::nextafter(rb, std::numeric_limits<float>::infinity());
+            sph_cull.push_back(make_float4(px, py, pz, (float)(pp - (double)rb * rb)));
+            sph_exact.push_back(make_float4(px, py, pz, rb));
+            sph_box.push_back(make_float4(hx, hy, hz, 1.0f));
+            sph_obj.push_back((int32_t)k);
+            obj_geom[k] = make_float4(px, py, pz, 0);
+            obj_aux[k] = make_float4(hx, hy, hz, 0);
+            if (pp + (double)rb * rb > c2max) c2max = pp + (double)rb * rb;
         } else if (o.shape == RT_SHAPE_PLANE) {
             pl_pos.push_back(make_float4(px, py, pz, 0));
             pl_nrm.push_back(make_float4(o.shape_param[0], o.shape_param[1], o.shape_param[2], 0));
@@ -508,6 +526,7 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     for (uint32_t k = n_sph; k < n_pad; ++k) {
         sph_cull.push_back(make_float4(0, 0, 0, inf));  // never passes the filter
         sph_exact.push_back(make_float4(0, 0, 0, 1));
+        sph_box.push_back(make_float4(0, 0, 0, 0));
         sph_obj.push_back(-1);
     }
     float c2max_f = (float)c2max;
@@ -523,6 +542,7 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     };
     up(sph_cull, &d.sph_cull);
     up(sph_exact, &d.sph_exact);
+    up(sph_box, &d.sph_box);
     up(sph_obj, &d.sph_obj);
     up(pl_pos, &d.pl_pos);
     up(pl_nrm, &d.pl_nrm);

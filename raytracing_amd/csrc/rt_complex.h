@@ -416,6 +416,10 @@ __device__ __noinline__ float cx_prefix_closest(const DevScene& sc, BvhLds top, 
             const float4 g = sc.obj_geom[j];
             float t;
             if (sphere_first_t(o, d, a, f3(g.x, g.y, g.z), g.w, t) && t < best) best = t;
+        } else if (sc.obj_shape[j] == RT_SHAPE_BOX) {
+            const float4 g = sc.obj_geom[j], hb = sc.obj_aux[j];
+            float t;
+            if (box_first_t(o, d, f3(g.x, g.y, g.z), f3(hb.x, hb.y, hb.z), t) && t < best) best = t;
         } else {
             const float4 g = sc.obj_geom[j], n4 = sc.obj_aux[j];
             const F3 n = f3(n4.x, n4.y, n4.z), lo = o - f3(g.x, g.y, g.z);

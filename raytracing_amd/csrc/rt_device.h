@@ -102,6 +102,47 @@ __device__ __forceinline__ bool sphere_first_t(F3 o, F3 d, float a, F3 pos, floa
     return false;
 }
 
+// First element of the reference's hit list for Transform(AxisAlignedBox(-half, half)) with rotation 0
+// (transform.rs:22-23: local origin = o - position exactly, local direction = d; axis_aligned_box.rs:12-41): the slab
+// test started from (t_min, +inf) and the entry hit at tmin.  A ray that starts inside "enters" at t_min itself, as in the
+// reference.  (With the reference's finite t_max the entry is the same number or the box yields nothing because
+// tmax <= tmin, i.e. it could not have won: DESIGN.md §4.2.)
+__device__ __forceinline__ bool box_first_t(F3 o, F3 d, F3 pos, F3 half, float& t_out)
+{
+    const F3 lo = o - pos;
+    float tmin = kTMin, tmax = __builtin_inff();
+    const float lo_c[3] = {lo.x, lo.y, lo.z}, d_c[3] = {d.x, d.y, d.z}, h_c[3] = {half.x, half.y, half.z};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float inv_d = 1.0f / d_c[i];
+        float t0 = (-h_c[i] - lo_c[i]) * inv_d;
+        float t1 = (h_c[i] - lo_c[i]) * inv_d;
+        if (inv_d < 0.0f) {
+            const float s = t0;
+            t0 = t1;
+            t1 = s;
+        }
+        tmin = __builtin_fmaxf(tmin, t0);  // f32::max / f32::min: the non-NaN operand wins
+        tmax = __builtin_fminf(tmax, t1);
+        if (tmax <= tmin) return false;
+    }
+    t_out = tmin;
+    return true;
+}
+// AxisAlignedBox::calculate_normal (axis_aligned_box.rs:70-95) at local point p: first face within 1e-4, else zero
+__device__ __forceinline__ F3 box_face_normal(F3 p, F3 half)
+{
+    const float eps = 1e-4f;
+    const F3 pa = p + half, pb = p - half;  // p - min, p - max with min = -half
+    if (__builtin_fabsf(pa.x) < eps) return f3(-1.f, 0.f, 0.f);
+    if (__builtin_fabsf(pb.x) < eps) return f3(1.f, 0.f, 0.f);
+    if (__builtin_fabsf(pa.y) < eps) return f3(0.f, -1.f, 0.f);
+    if (__builtin_fabsf(pb.y) < eps) return f3(0.f, 1.f, 0.f);
+    if (__builtin_fabsf(pa.z) < eps) return f3(0.f, 0.f, -1.f);
+    if (__builtin_fabsf(pb.z) < eps) return f3(0.f, 0.f, 1.f);
+    return f3(0.f, 0.f, 0.f);
+}
+
 template <int R>
 struct WaveLds {
     float stash[7][R * 64];            // o.xyz, d.xyz, a per slot
@@ -120,9 +161,12 @@ __device__ __forceinline__ void confirm_batch(WaveLds<R>& w, const DevScene& sc,
             F3 o = f3(w.stash[0][slot], w.stash[1][slot], w.stash[2][slot]);
             F3 d = f3(w.stash[3][slot], w.stash[4][slot], w.stash[5][slot]);
             float a = w.stash[6][slot];
-            float4 s = sc.sph_exact[j];
+            const float4 s = sc.sph_exact[j];
+            const float4 hb = sc.sph_box[j];  // {half extents, 1} when entry j is the bounding sphere of a rotation-0 Box, else 0
             float t;
-            if (sphere_first_t(o, d, a, f3(s.x, s.y, s.z), s.w, t)) atomicMin(&w.best[slot], pack_key(t, sc.sph_obj[j]));
+            const bool hit = hb.w != 0.0f ? (box_first_t(o, d, f3(s.x, s.y, s.z), f3(hb.x, hb.y, hb.z), t) && t < __builtin_inff())
+                                          : sphere_first_t(o, d, a, f3(s.x, s.y, s.z), s.w, t);
+            if (hit) atomicMin(&w.best[slot], pack_key(t, sc.sph_obj[j]));
         }
     }
 }
@@ -494,7 +538,11 @@ __device__ __forceinline__ Shade shade_hit(const DevScene& sc, F3 o, F3 d, float
         const F3 lo = o - pos;
         const F3 pl = lo + h.t * d;  // local hit point (sphere.rs:28 / plane.rs:32)
         F3 nl;
-        if (sc.obj_shape[h.obj] == RT_SHAPE_SPHERE) {
+        if (sc.obj_shape[h.obj] == RT_SHAPE_BOX) {  // axis_aligned_box.rs:33-41: the entry normal is kept as computed, not turned against the ray
+            const float4 hb = sc.obj_aux[h.obj];
+            nl = box_face_normal(pl, f3(hb.x, hb.y, hb.z));
+            h.front = dot(d, nl) < 0.0f;
+        } else if (sc.obj_shape[h.obj] == RT_SHAPE_SPHERE) {
             F3 outward = pl / g.w;  // (point - 0) / radius, sphere.rs:29
             h.front = dot(d, outward) < 0.0f;
             nl = h.front ? outward : -outward;

@@ -53,13 +53,14 @@ constexpr uint32_t kBvhLdsNodes = 85;  // 1 + 4 + 16 + 64: the top four levels o
 // Flattened scene as the kernels see it (all pointers are device memory).
 struct DevScene {
     const float4* sph_cull;   // [n_sph_pad] {px, py, pz, K = |p|^2 - r^2}; padding has K = +inf
-    const float4* sph_exact;  // [n_sph_pad] {px, py, pz, r}
+    const float4* sph_exact;  // [n_sph_pad] {px, py, pz, r}; for a rotation-0 Box: its centre and bounding radius
+    const float4* sph_box;    // [n_sph_pad] {half extents, 1} for such a Box, zero for spheres
     const int32_t* sph_obj;   // [n_sph_pad] object-list index of sphere j (increasing in j)
     const float4* pl_pos;     // [n_pl] {px, py, pz, 0}
     const float4* pl_nrm;     // [n_pl] {nx, ny, nz, 0} (not normalised, as configured)
     const int32_t* pl_obj;    // [n_pl]
     const float4* obj_geom;   // [n_obj] sphere: {px,py,pz,r}; plane: {px,py,pz,0}
-    const float4* obj_aux;    // [n_obj] plane: {nx,ny,nz,0}
+    const float4* obj_aux;    // [n_obj] plane: {nx,ny,nz,0}; scan-path box: {half extents, 0}
     const uint2* obj_mat;     // [n_obj] {material kind, bits of material param}
     const uint32_t* obj_shape;  // [n_obj]
     const int32_t* obj_cx;      // [n_obj] index into cx_objs for objects off the scan path, -1 for scan-path spheres / planes
