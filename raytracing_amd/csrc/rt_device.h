@@ -487,6 +487,88 @@ __device__ __forceinline__ void scan_tile(const float4* tile, unsigned count, fl
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wave-level cull of the shared-origin table.  The work units of one slot group are dealt to neighbouring
+// lanes, so the 64 rays of a group cover a short run of generator cells, and they keep those cells for unit_samples steps.
+// A sphere whose affine form cannot reach the smallest threshold of the group anywhere in the group's bounding box of cell
+// indices cannot pass for any of its rays, in any of those steps; the few that can are copied to a per-group LDS list once,
+// and the primary scan of the following steps reads that list instead of the whole table.  The per-ray test on the list is
+// the same expression as in affine_h4, so every ray sees exactly the candidates it would have seen in the full scan.
+//
+// Bound.  h(i, j) = fl(fl(a + j c) + i b) is the value the per-ray test computes.  With T = |a| + jmax |c| + imax |b| and
+// u = 2^-24, |h(i, j) - (a + j c + i b)| <= 2.01 u T for every cell of the box, and the same holds for the centre value hc,
+// so |h(i, j)| <= |hc| + dj |c| + di |b| + 4.02 u T with (di, dj) the half extents.  The code evaluates that bound with FMAs
+// (three more roundings, each below u T), adds 8 u T instead of 4.02 u T and scales by 1 + 2^-20: a sphere is dropped only
+// if even the inflated bound stays below the smallest threshold.  inf entries ("always") and NaNs survive.
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) const float LdsF;
+constexpr unsigned kCullCap = 40;  // list entries per slot group; a group that needs more falls back to the full table scan
+
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = __builtin_fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// table: packed {A', B', C'} per sphere (LDS or global memory), n_pad entries.  Returns the number of surviving spheres;
+// list[0 .. min(n, kCullCap)) = {A', B', C', sphere index bits}.  n > kCullCap: the list is incomplete, scan the table.
+template <typename TablePtr>
+__device__ __forceinline__ unsigned cull_group(TablePtr table, unsigned n_pad, float ci, float cj, float lt, bool live, float4* list, unsigned lane)
+{
+    const float inf = __builtin_inff();
+    const float imin = wave_min(live ? ci : inf), imax = wave_max(live ? ci : -inf);
+    const float jmin = wave_min(live ? cj : inf), jmax = wave_max(live ? cj : -inf);
+    const float lmin = wave_min(live ? lt : inf);
+    if (!(imin <= imax)) return 0;  // no live slot in this group
+    // cell indices are integers below 2^24: sums, differences and halves are exact
+    const float ic = 0.5f * (imin + imax), di = 0.5f * (imax - imin), jc = 0.5f * (jmin + jmax), dj = 0.5f * (jmax - jmin);
+    unsigned n = 0;
+    for (unsigned base = 0; base < n_pad; base += 64) {
+        const unsigned k = base + lane;
+        bool pass = false;
+        float a = 0.f, b = 0.f, c = 0.f;
+        if (k < n_pad) {
+            a = table[3u * k];
+            b = table[3u * k + 1];
+            c = table[3u * k + 2];
+            const float fa = __builtin_fabsf(a), fb = __builtin_fabsf(b), fc = __builtin_fabsf(c);
+            const float hc = __builtin_fmaf(ic, b, __builtin_fmaf(jc, c, a));
+            float U = __builtin_fmaf(di, fb, __builtin_fmaf(dj, fc, __builtin_fabsf(hc)));
+            const float T = __builtin_fmaf(imax, fb, __builtin_fmaf(jmax, fc, fa));
+            U = __builtin_fmaf(T, 0x1p-21f, U);
+            pass = !(U * (1.0f + 0x1p-20f) < lmin);
+        }
+        const unsigned long long mask = __ballot(pass);
+        if (mask) {
+            const unsigned pos = n + mbcnt64(mask);
+            if (pass && pos < kCullCap) list[pos] = make_float4(a, b, c, __uint_as_float(k));
+            n += (unsigned)__builtin_popcountll(mask);
+        }
+    }
+    return n;
+}
+
+// The primary scan of slot group r over its cull list: same expression, same threshold as affine_h4 / affine_push4.
+template <int R>
+__device__ __forceinline__ void scan_cull_list(const float4* list, unsigned n, int r, float ci, float cj, float lt, WaveLds<R>& w, const DevScene& sc,
+                                               unsigned& head, unsigned& tail, unsigned lane)
+{
+    for (unsigned k = 0; k < n; ++k) {
+        const float4 e = list[k];
+        const float h = __builtin_fmaf(ci, e.y, __builtin_fmaf(cj, e.z, e.x));
+        const bool pass = __builtin_fabsf(h) >= lt;
+        const unsigned long long mask = __ballot(pass);
+        if (mask) push_candidates<R>(w, sc, mask, pass, (unsigned)r * 64u, __float_as_uint(e.w), head, tail, lane);
+    }
+}
+
 // Planes are few: exact test inline (Transform(Plane) with rotation 0: transform.rs:22-23, plane.rs:14-27).
 __device__ __forceinline__ unsigned long long planes_min_key(const DevScene& sc, F3 o, F3 d, unsigned long long key)
 {

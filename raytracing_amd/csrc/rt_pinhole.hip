@@ -70,6 +70,7 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
     extern __shared__ float4 tiles[];  // [n_sph_pad] general {p, K}, then 3 floats per sphere {A, B, C} / sK (LDS mode), then the BVH top
     __shared__ WaveLds<R> wl[kPinThreads / 64];
     __shared__ float4 stage_all[STREAM ? (kPinThreads / 64) * 128 : 1];
+    __shared__ float4 cull_all[kPinThreads / 64][R][kCullCap];  // per wave and slot group: the spheres its current cells can reach
 
     const unsigned lane = lane_id();
     const unsigned wave = threadIdx.x >> 6;
@@ -116,6 +117,14 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
     }
     unsigned long long my_segments = 0;
     bool exhausted = false, prim_done = false;
+    // cull lists (wave-uniform state): entries in the list, and whether the group's cells changed since it was built
+    unsigned n_cull[R];
+    bool cull_stale[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        n_cull[r] = 0;
+        cull_stale[r] = true;
+    }
     const unsigned long long total_units = (unsigned long long)p.cell_count * p.units_per_cell;
     const uint32_t max_b = p.st.max_bounces;
 
@@ -144,6 +153,7 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                     base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
                            __builtin_amdgcn_readfirstlane((unsigned)base);
                     if (base + cnt >= total_units) exhausted = true;
+                    cull_stale[r] = true;
                     if (need_unit) {
                         unsigned long long unit = base + mbcnt64(need);
                         if (unit < total_units) {
@@ -191,7 +201,24 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 c.lt[r] = live[r] ? __builtin_sqrtf(dot(dv, dv)) * (1.0f - 0x1p-20f) : __builtin_nanf("");  // NaN: dead slots never pass
             }
             wave_lds_sync();
-            scan_tile<R, 1, STREAM>(tileP, n_pad, stage, c, w, sc, head, tail, lane);
+            // groups whose cells changed rebuild their list (once per unit_samples steps when the units are of equal length)
+            bool listed = true;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (cull_stale[r]) {
+                    if (STREAM) n_cull[r] = cull_group(reinterpret_cast<const float*>(p.prim_table), n_pad, c.ci[r], c.cj[r], c.lt[r], live[r], cull_all[wave][r], lane);
+                    else n_cull[r] = cull_group((LdsF*)(tiles + n_pad), n_pad, c.ci[r], c.cj[r], c.lt[r], live[r], cull_all[wave][r], lane);
+                    cull_stale[r] = false;
+                }
+                listed &= n_cull[r] <= kCullCap;
+            }
+            if (listed) {
+                wave_lds_sync();
+#pragma unroll
+                for (int r = 0; r < R; ++r) scan_cull_list<R>(cull_all[wave][r], n_cull[r], r, c.ci[r], c.cj[r], c.lt[r], w, sc, head, tail, lane);
+            } else {
+                scan_tile<R, 1, STREAM>(tileP, n_pad, stage, c, w, sc, head, tail, lane);
+            }
         } else {
             // ================= continuing-ray step =================
             const unsigned n_pop = sec_count < 64u * R ? sec_count : 64u * R;
