@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "rt_host_bvh.h"
+#include "rt_host_grid.h"
 #include "rt_host_shapes.h"
 #include "rt_internal.h"
 
@@ -284,12 +285,13 @@ int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream,
             if (v > c2) c2 = v;
         }
         p.prim_margin = (float)(c2 * 64.0 * 0x1p-24 * (1.0 + 1e-6));
+        p.grid_mode = rt::pinhole_grid_mode(p);  // decides the LDS layout, hence the resident blocks the rings are sized for
         if (int rc = ensure_scratch(ws, ws.secq, ws.secq_bytes, g_ctx.secq, g_ctx.secq_bytes, rt::pinhole_secq_bytes(p, g_ctx.n_cu),
                                     "the continuing-ray rings"))
             return rc;
         p.secq = ws.secq;
         if (int rc = ensure_scratch(ws, ws.prim_table, ws.prim_table_bytes, g_ctx.prim_table, g_ctx.prim_table_bytes,
-                                    rt::pinhole_table_bytes(p), "the streamed sphere table"))
+                                    rt::pinhole_table_bytes(p), "the shared-origin table"))
             return rc;
         p.prim_table = ws.prim_table;
         HIP_TRY(rt::launch_pinhole(p, g_ctx.n_cu, g_ctx.device, stream));
@@ -531,6 +533,9 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     }
     float c2max_f = (float)c2max;
     if ((double)c2max_f < c2max) c2max_f = std::nextafter(c2max_f, inf);
+    // uniform grid for the continuing rays of the Projector kernel (disabled for small or unsuitable scenes)
+    rt::host::GridHost grid = rt::host::build_grid(sph_exact, sph_box, n_sph);
+    if (grid.items.size() & 1) grid.items.push_back(0);  // the kernel copies the item list in whole words
 
     rt_scene* s = new rt_scene;
     rt::DevScene& d = s->dev;
@@ -556,6 +561,11 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     up(cx_objs, &d.cx_objs);
     up(bvh_nodes, &d.bvh_nodes);
     up(tris, &d.tris);
+    d.grid = grid.g;
+    if (grid.g.enabled) {
+        up(grid.cells, &d.grid.cells);
+        up(grid.items, &d.grid.items);
+    }
     if (e != hipSuccess) {
         free_scene(s);
         return fail_hip(e, "scene upload");

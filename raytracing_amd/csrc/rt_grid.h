@@ -1,0 +1,173 @@
+// rt_grid.h — continuing rays of the Projector kernel walk a uniform grid over the scan-path spheres.
+//
+// A ray that left a surface has no shared origin to exploit, and scanning the whole table for it costs eight VALU
+// instructions per sphere.  Instead every lane steps its ray through the grid's cells (3-D DDA) and looks only at the
+// spheres registered there.  Nothing about the RESULT changes hands: a sphere whose reference discriminant (sphere.rs:13-18,
+// computed here with the same operations on the same operands as sphere_first_t) is not negative goes to the wave's
+// candidate queue, and confirm_batch runs the exact sequence for it as it does for the table scan; a box entry goes there
+// unconditionally.  The walk only has to guarantee that the entry which ends up closest is seen, and it may stop early:
+//   * registration (rt_host_grid.h) puts every entry into each cell within E of its surface, E >= the distance by which the
+//     float discriminant can accept a ray outside the sphere + the error of the returned t + the walk's placement error;
+//   * a sphere whose first root t1 is safely inside (t_min, inf) WILL be confirmed with a t within `slack` of the fast
+//     estimate made here, so `bound` = estimate + slack is an upper bound of the winning t, and once the walk has covered
+//     the ray up to bound + slack every entry that could still win has been seen.
+// Control flow is wave-uniform (the loop runs while any lane is walking), so the candidate queue works as in the table scan.
+#pragma once
+#include "rt_device.h"
+
+namespace rt {
+
+typedef __attribute__((address_space(3))) const uint32_t LdsU32;
+typedef __attribute__((address_space(3))) const uint16_t LdsU16;
+typedef float RtGV4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const RtGV4 LdsGV4;
+
+__device__ __forceinline__ float4 grid_sphere(const float4* t, unsigned j) { return t[j]; }
+__device__ __forceinline__ float4 grid_sphere(LdsGV4* t, unsigned j)
+{
+    const RtGV4 v = t[j];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// rays whose origin the grid's error budget covers (rt_host_grid.h: |o - centre| <= 2 * radius)
+__device__ __forceinline__ bool grid_admits(const DevGrid& g, F3 o)
+{
+    const F3 oc = o - f3(g.centre[0], g.centre[1], g.centre[2]);
+    return dot(oc, oc) <= g.origin_r2;
+}
+
+template <int R, typename CellPtr, typename ItemPtr, typename SphPtr>
+__device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemPtr items, SphPtr sph, F3 o, F3 d, float a, bool live,
+                                          unsigned slot_base, WaveLds<R>& w, const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane,
+                                          unsigned long long& dbg)
+{
+    const float inf = __builtin_inff();
+    const float rs = __builtin_amdgcn_rsqf(a);  // ~ 1 / |d|
+    const F3 oc = o - f3(g.centre[0], g.centre[1], g.centre[2]);
+    const float slack = g.slack_k * (__builtin_amdgcn_sqrtf(dot(oc, oc)) + g.radius) * rs;
+    const float ia = __builtin_amdgcn_rcpf(a);
+
+    // entry: slab test against the grid bounds (fmax / fmin drop NaNs; directions below 1e-30 count as parallel)
+    bool active = live;
+    float t0 = 0.0f, t1 = inf;
+    float tdx = inf, tdy = inf, tdz = inf, ivx = 0.f, ivy = 0.f, ivz = 0.f;
+    if (__builtin_fabsf(d.x) >= 1e-30f) {
+        ivx = __builtin_amdgcn_rcpf(d.x);
+        const float ta = (g.lo[0] - o.x) * ivx, tb = (g.hi[0] - o.x) * ivx;
+        t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
+        t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
+        tdx = g.cell * __builtin_fabsf(ivx);
+    } else if (o.x < g.lo[0] || o.x > g.hi[0]) active = false;
+    if (__builtin_fabsf(d.y) >= 1e-30f) {
+        ivy = __builtin_amdgcn_rcpf(d.y);
+        const float ta = (g.lo[1] - o.y) * ivy, tb = (g.hi[1] - o.y) * ivy;
+        t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
+        t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
+        tdy = g.cell * __builtin_fabsf(ivy);
+    } else if (o.y < g.lo[1] || o.y > g.hi[1]) active = false;
+    if (__builtin_fabsf(d.z) >= 1e-30f) {
+        ivz = __builtin_amdgcn_rcpf(d.z);
+        const float ta = (g.lo[2] - o.z) * ivz, tb = (g.hi[2] - o.z) * ivz;
+        t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
+        t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
+        tdz = g.cell * __builtin_fabsf(ivz);
+    } else if (o.z < g.lo[2] || o.z > g.hi[2]) active = false;
+    if (t0 > t1 + slack) active = false;  // misses the bounds by more than the slack: touches no registered box
+
+    // start cell (clamped: the entry point may sit a rounding error outside) and the first boundary crossings
+    const float ex = __builtin_fmaf(t0, d.x, o.x), ey = __builtin_fmaf(t0, d.y, o.y), ez = __builtin_fmaf(t0, d.z, o.z);
+    const int dimx = (int)g.dim[0], dimy = (int)g.dim[1], dimz = (int)g.dim[2];
+    int cx = (int)__builtin_floorf((ex - g.lo[0]) * g.inv_cell), cy = (int)__builtin_floorf((ey - g.lo[1]) * g.inv_cell),
+        cz = (int)__builtin_floorf((ez - g.lo[2]) * g.inv_cell);
+    cx = cx < 0 ? 0 : (cx >= dimx ? dimx - 1 : cx);
+    cy = cy < 0 ? 0 : (cy >= dimy ? dimy - 1 : cy);
+    cz = cz < 0 ? 0 : (cz >= dimz ? dimz - 1 : cz);
+    const int sx = d.x > 0.0f ? 1 : -1, sy = d.y > 0.0f ? 1 : -1, sz = d.z > 0.0f ? 1 : -1;
+    float tmx = tdx < inf ? (g.lo[0] + (float)(cx + (sx > 0 ? 1 : 0)) * g.cell - o.x) * ivx : inf;
+    float tmy = tdy < inf ? (g.lo[1] + (float)(cy + (sy > 0 ? 1 : 0)) * g.cell - o.y) * ivy : inf;
+    float tmz = tdz < inf ? (g.lo[2] + (float)(cz + (sz > 0 ? 1 : 0)) * g.cell - o.z) * ivz : inf;
+
+    float bound = inf;  // upper bound of the t that will win, from spheres already queued
+    unsigned k = 0, cnt = 0, start = 0, last = 0xffffffffu;
+    bool first = true;  // the start cell's record has not been read yet
+#if RT_DBG_WALK == 4
+    if (lane == 0) ++dbg;
+#endif
+    while (__ballot(active)) {
+        bool pass = false;
+        unsigned j = 0;
+#if RT_DBG_WALK == 1
+        if (lane == 0) ++dbg;
+#endif
+        if (active) {
+#if RT_DBG_WALK == 2
+            ++dbg;
+#endif
+            // one entry of the current cell (if any is left) ...
+            if (k < cnt) {
+                const unsigned it = items[start + k];
+                ++k;
+                j = it & 0x7fffu;
+                if (j != last) {  // the same entry is often registered in the next cell too
+                    last = j;
+                    if (it & 0x8000u) {
+                        pass = true;  // box: the exact slab test decides
+                    } else {
+                        // sphere.rs:13-18, operation for operation as in sphere_first_t
+                        const float4 s = grid_sphere(sph, j);
+#if RT_DBG_WALK == 3
+                        ++dbg;
+#endif
+                        const F3 lo = o - f3(s.x, s.y, s.z);
+                        const float half_b = dot(lo, d);
+                        const float c = dot(lo, lo) - s.w * s.w;
+                        const float disc = half_b * half_b - a * c;
+                        if (!(disc < 0.0f)) {
+                            pass = true;
+                            const float sq = __builtin_amdgcn_sqrtf(disc);
+                            const float e1 = (-half_b - sq) * ia;
+                            if (e1 > kTMin + slack) bound = __builtin_fminf(bound, e1 + slack);
+                            else if (e1 < kTMin - slack && disc > 1e-6f) {
+                                const float e2 = (-half_b + sq) * ia;
+                                if (e2 > kTMin + slack) bound = __builtin_fminf(bound, e2 + slack);
+                            }
+                        }
+                    }
+                }
+            }
+            // ... and, once the cell is used up, the step to the next one in the same pass (a lane's pass count is the larger
+            // of its cells and its entries, not their sum)
+            if (k >= cnt) {
+                if (!first) {
+                    const float texit = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
+                    if (bound < texit - slack) {
+                        active = false;  // everything that can still win starts before texit - slack and has been seen
+                    } else {
+    #if RT_DBG_WALK == 5
+                        ++dbg;
+#endif
+                        const bool stepx = tmx <= tmy && tmx <= tmz, stepy = !stepx && tmy <= tmz, stepz = !stepx && !stepy;
+                        cx += stepx ? sx : 0;
+                        cy += stepy ? sy : 0;
+                        cz += stepz ? sz : 0;
+                        tmx += stepx ? tdx : 0.0f;
+                        tmy += stepy ? tdy : 0.0f;
+                        tmz += stepz ? tdz : 0.0f;
+                        if ((unsigned)cx >= (unsigned)dimx || (unsigned)cy >= (unsigned)dimy || (unsigned)cz >= (unsigned)dimz) active = false;
+                    }
+                }
+                first = false;
+                if (active) {
+                    const unsigned rec = cells[((unsigned)cz * (unsigned)dimy + (unsigned)cy) * (unsigned)dimx + (unsigned)cx];
+                    start = rec & 0xfffffu;
+                    cnt = rec >> 20;
+                    k = 0;
+                }
+            }
+        }
+        const unsigned long long mask = __ballot(pass);
+        if (mask) push_candidates<R>(w, sc, mask, pass, slot_base, j, head, tail, lane);
+    }
+}
+
+}  // namespace rt

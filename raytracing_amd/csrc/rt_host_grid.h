@@ -1,0 +1,149 @@
+// rt_host_grid.h — host-side build of the uniform grid the Projector kernel's continuing rays walk.
+//
+// Every scan-path entry j (a sphere, or the bounding sphere of a rotation-0 box) is registered in each cell that its box
+// [p - (r + E), p + (r + E)] touches.  E covers everything the float arithmetic of the device can get wrong about WHERE a hit
+// is: the reference's discriminant test (sphere.rs:13-18) accepts rays that pass up to sqrt(25 u) |o - p| outside the sphere
+// (u = 2^-24; 25 u |o - p|^2 |d|^2 bounds the rounding of its discriminant), the t it returns is off by at most as much again,
+// and the cell walk itself places points with an error of a few u times the coordinates.  With every admitted ray origin
+// within 2 * radius of the grid centre, |o - p| <= 3 * radius =: D, and E = 3e-3 * D >= 2 * sqrt(25 u) * D + the walk's error.
+// Rays that start farther away do not use the grid (DevGrid::origin_r2).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+#include "rt_internal.h"
+
+namespace rt {
+namespace host {
+
+struct GridHost {
+    DevGrid g{};                  // pointers left null; the caller uploads cells / items
+    std::vector<uint32_t> cells;
+    std::vector<uint16_t> items;
+};
+
+constexpr uint32_t kGridMinSpheres = 96;      // below this the table scan is cheaper than the walk
+constexpr uint32_t kGridMaxSpheres = 32767;   // 15-bit item indices
+constexpr uint32_t kGridMaxDim = 96;
+
+// sph_exact[0 .. n): {p, r}; sph_box[j].w != 0 marks a box entry.
+inline GridHost build_grid(const std::vector<float4>& sph_exact, const std::vector<float4>& sph_box, uint32_t n)
+{
+    GridHost out;
+    if (n < kGridMinSpheres || n > kGridMaxSpheres) return out;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t j = 0; j < n; ++j) {
+        const double p[3] = {sph_exact[j].x, sph_exact[j].y, sph_exact[j].z}, r = std::fabs((double)sph_exact[j].w);
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2]) || !std::isfinite(r)) return out;
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], p[a] - r);
+            hi[a] = std::max(hi[a], p[a] + r);
+        }
+    }
+    double diag2 = 0.0, c[3];
+    for (int a = 0; a < 3; ++a) {
+        diag2 += (hi[a] - lo[a]) * (hi[a] - lo[a]);
+        c[a] = 0.5 * (lo[a] + hi[a]);
+    }
+    const double radius0 = 0.5 * std::sqrt(diag2);
+    if (!(radius0 > 0.0) || !(radius0 < 1e15)) return out;
+    // magnitudes: the float coordinates the device works with must resolve E
+    double cmax = 0.0;
+    for (int a = 0; a < 3; ++a) cmax = std::max(cmax, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+    const double D = 3.0 * radius0 * 1.01;
+    const double E = 3e-3 * D;
+    if (!(E > 64.0 * 0x1p-24 * (cmax + 3.0 * radius0))) return out;  // scene far from the coordinate origin relative to its size
+    for (int a = 0; a < 3; ++a) {
+        lo[a] -= 2.0 * E;
+        hi[a] += 2.0 * E;
+    }
+    double vol = 1.0, ext[3];
+    for (int a = 0; a < 3; ++a) {
+        ext[a] = hi[a] - lo[a];
+        vol *= ext[a];
+    }
+    double cs = std::cbrt(vol / (double)n);
+    // every cell at least as wide as the typical inflated sphere box would make a sphere span 8+ cells: keep cells >= 2 E
+    cs = std::max(cs, 2.0 * E);
+    uint32_t dim[3];
+    for (;;) {
+        bool ok = true;
+        for (int a = 0; a < 3; ++a) {
+            const double d = std::ceil(ext[a] / cs);
+            dim[a] = (uint32_t)std::max(1.0, d);
+            if (d > (double)kGridMaxDim) ok = false;
+        }
+        if (ok) break;
+        cs *= 1.25;
+    }
+    const float csf = (float)cs, inv = 1.0f / csf;
+    const uint64_t n_cells = (uint64_t)dim[0] * dim[1] * dim[2];
+    std::vector<uint32_t> count(n_cells, 0);
+    // cell range of a sphere: computed in double from the same float cell size the device uses, one extra cell of safety is
+    // not needed because E already contains the device's placement error
+    auto range = [&](uint32_t j, int a, uint32_t& c0, uint32_t& c1) {
+        const double p = a == 0 ? sph_exact[j].x : a == 1 ? sph_exact[j].y : sph_exact[j].z;
+        const double r = std::fabs((double)sph_exact[j].w) + E;
+        const double f0 = std::floor((p - r - lo[a]) / (double)csf), f1 = std::floor((p + r - lo[a]) / (double)csf);
+        c0 = (uint32_t)std::min(std::max(f0, 0.0), (double)dim[a] - 1.0);
+        c1 = (uint32_t)std::min(std::max(f1, 0.0), (double)dim[a] - 1.0);
+    };
+    uint64_t total = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        uint32_t x0, x1, y0, y1, z0, z1;
+        range(j, 0, x0, x1);
+        range(j, 1, y0, y1);
+        range(j, 2, z0, z1);
+        total += (uint64_t)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1);
+        if (total > (uint64_t)16 * n + 4096) return out;  // a few huge spheres would sit in every cell: not worth a grid
+        for (uint32_t z = z0; z <= z1; ++z)
+            for (uint32_t y = y0; y <= y1; ++y)
+                for (uint32_t x = x0; x <= x1; ++x) ++count[((uint64_t)z * dim[1] + y) * dim[0] + x];
+    }
+    if (total >= (1u << 20)) return out;
+    out.cells.resize(n_cells);
+    uint32_t run = 0;
+    for (uint64_t k = 0; k < n_cells; ++k) {
+        if (count[k] > 4095) return GridHost{};
+        out.cells[k] = run | (count[k] << 20);
+        run += count[k];
+        count[k] = 0;
+    }
+    out.items.resize(total ? total : 1);
+    for (uint32_t j = 0; j < n; ++j) {  // ascending j inside every cell
+        uint32_t x0, x1, y0, y1, z0, z1;
+        range(j, 0, x0, x1);
+        range(j, 1, y0, y1);
+        range(j, 2, z0, z1);
+        const uint16_t item = (uint16_t)(j | (sph_box[j].w != 0.0f ? 0x8000u : 0u));
+        for (uint32_t z = z0; z <= z1; ++z)
+            for (uint32_t y = y0; y <= y1; ++y)
+                for (uint32_t x = x0; x <= x1; ++x) {
+                    const uint64_t k = ((uint64_t)z * dim[1] + y) * dim[0] + x;
+                    out.items[(out.cells[k] & 0xfffffu) + count[k]++] = item;
+                }
+    }
+    DevGrid& g = out.g;
+    for (int a = 0; a < 3; ++a) {
+        g.lo[a] = (float)lo[a];
+        g.hi[a] = (float)(lo[a] + (double)csf * dim[a]);
+        if ((double)g.hi[a] < hi[a]) g.hi[a] = std::nextafter((float)hi[a], std::numeric_limits<float>::infinity());
+        g.dim[a] = dim[a];
+        g.centre[a] = (float)c[a];
+    }
+    g.cell = csf;
+    g.inv_cell = inv;
+    g.radius = (float)(radius0 * 1.01);
+    g.origin_r2 = (float)(4.0 * radius0 * radius0);  // |o - centre| <= 2 * radius0
+    g.slack_k = 2e-3f;
+    g.n_cells = (uint32_t)n_cells;
+    g.n_items = (uint32_t)total;
+    g.enabled = 1;
+    return out;
+}
+
+}  // namespace host
+}  // namespace rt

@@ -50,6 +50,22 @@ struct TriDev {
 constexpr int kBvhStack = 64;
 constexpr uint32_t kBvhLdsNodes = 85;  // 1 + 4 + 16 + 64: the top four levels of a 4-wide tree, 10,880 bytes
 
+// Uniform grid over the scan-path spheres / box bounding spheres: continuing rays of the Projector kernel
+// walk it cell by cell instead of scanning the whole table.  Built on the host when the scene is created (rt_host_grid.h).
+struct DevGrid {
+    const uint32_t* cells;   // [dim x * dim y * dim z] first item (bits 0..19) | item count (bits 20..31); x fastest
+    const uint16_t* items;   // sphere index j (bits 0..14) | bit 15: entry j is a box (no discriminant pre-test)
+    float lo[3], hi[3];      // bounds of the grid (contain every registered, inflated sphere box)
+    float cell, inv_cell;    // cubic cells
+    uint32_t dim[3];
+    float centre[3];
+    float radius;            // half diagonal of the bounds
+    float origin_r2;         // rays whose origin lies farther than sqrt(origin_r2) from `centre` take the table scan instead
+    float slack_k;           // t slack of a ray = slack_k * (|o - centre| + radius) / |d|
+    uint32_t n_cells, n_items;
+    uint32_t enabled;        // 0: no grid for this scene (few spheres, non-finite data, oversized lists)
+};
+
 // Flattened scene as the kernels see it (all pointers are device memory).
 struct DevScene {
     const float4* sph_cull;   // [n_sph_pad] {px, py, pz, K = |p|^2 - r^2}; padding has K = +inf
@@ -72,6 +88,7 @@ struct DevScene {
     uint32_t n_bvh_nodes;  // entries of bvh_nodes
     uint32_t n_sph, n_sph_pad, n_pl, n_obj;
     float c2max;  // >= max_j (|p_j|^2 + r_j^2), rounded up: magnitude bound used by the cull margin
+    DevGrid grid;
 };
 
 // Host-precomputed generator constants (scene_config.rs:70-72, 96-97): the per-component divisions and the
@@ -108,8 +125,9 @@ struct TraceParams {
     uint32_t* secq;     // per-wave rings of continuing rays: [grid waves][kSecFields][kSecCap] dwords
     float prim_margin;  // >= 64 u * max_j(|p_j - O|^2 + r_j^2): margin of the shared-origin filter
     float prim_rho;     // (3G + 7M) / d_min of the Projector: rounding of the affine numerator relative to |target - O|
-    float4* prim_table; // streamed mode only: 3 floats per sphere {A, B, C} / sK (packed), rebuilt per launch
+    float4* prim_table; // 3 floats per sphere {A, B, C} / sK (packed), rebuilt per launch; read by the per-wave cull
     uint32_t bvh_lds_nodes;  // pinhole kernel: the first this-many BvhNodes are copied into LDS (set by launch_pinhole)
+    uint32_t grid_mode;      // pinhole kernel: 0 no grid, 1 grid in LDS, 2 grid in global memory (pinhole_grid_mode, set before sizing)
 };
 
 constexpr unsigned kSecCap = 256;    // entries per wave ring (a primary step adds <= 128 to a residue < 128)
@@ -133,6 +151,7 @@ hipError_t launch_trace(const TraceParams& p, int n_cu, int device, hipStream_t 
 hipError_t launch_pinhole(const TraceParams& p, int n_cu, int device, hipStream_t stream);
 size_t pinhole_secq_bytes(const TraceParams& p, int n_cu);
 size_t pinhole_table_bytes(const TraceParams& p);
+uint32_t pinhole_grid_mode(const TraceParams& p);  // how this launch's continuing rays find their spheres (TraceParams::grid_mode)
 hipError_t launch_finalize(const unsigned long long* fb_q, float* fb, uint32_t* seg_count, uint64_t n_cells, uint32_t spp, hipStream_t stream);
 
 }  // namespace rt

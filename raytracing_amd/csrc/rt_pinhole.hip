@@ -11,6 +11,7 @@
 // busy.  Path values of primary misses are summed per work unit in registers; continuing paths add their
 // value and segment count with global atomics when they end (fixed-point sums: order-independent).
 #include "rt_complex.h"
+#include "rt_grid.h"
 
 #include <cstdlib>
 
@@ -63,7 +64,31 @@ __global__ void pinhole_table_kernel(const TraceParams p, float4* table)
     }
 }
 
-// STREAM = false: both tables (<= kTileSpheres spheres) live in LDS.  STREAM = true: both are streamed from global / L2.
+// Constants of the general filter (FLAVOR 0 of scan_step) for slot r.
+template <int R>
+__device__ __forceinline__ void general_consts(ScanConsts<R>& c, int r, F3 o, F3 d, float a, bool live, const DevScene& sc)
+{
+    const float rs = 1.0f / __builtin_sqrtf(a);
+    c.dh[r] = d * rs;
+    c.nod[r] = -dot(o, c.dh[r]);
+    const float oo = dot(o, o);
+    const float margin = kCullKappaU * (oo + sc.c2max);
+    c.s0[r] = live ? (oo - margin) : __builtin_inff();
+    c.pp[r] = f3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z);
+}
+
+// The table scan with the general filter.  from_global: the block's LDS holds the grid's tables instead of {p, K}, so this
+// (rare) scan reads them from global memory with wave-uniform loads.
+template <int R, bool STREAM>
+__device__ __forceinline__ void general_scan(bool from_global, const float4* tileG, unsigned n_pad, float4* stage, const ScanConsts<R>& c, WaveLds<R>& w,
+                                             const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane)
+{
+    if (STREAM) scan_tile<R, 0, true>(tileG, n_pad, stage, c, w, sc, head, tail, lane);
+    else if (from_global) scan_tile<R, 0, false>(sc.sph_cull, n_pad, stage, c, w, sc, head, tail, lane);
+    else scan_tile<R, 0, false>(tileG, n_pad, stage, c, w, sc, head, tail, lane);
+}
+
+// STREAM = false: the sphere tables (<= kTileSpheres spheres) live in LDS.  STREAM = true: both are streamed from global / L2.
 template <int R, bool STREAM, bool CX>
 __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TraceParams p)
 {
@@ -79,21 +104,23 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
     const DevScene& sc = p.sc;
     const unsigned n_pad = sc.n_sph_pad;
     const F3 O = f3(p.gen.a[0], p.gen.a[1], p.gen.a[2]);
+    // LDS tables (not streamed): grid mode 1 keeps {p, r} of every sphere, the grid's cells and its item lists; otherwise the
+    // general filter's {p, K}.  The shared-origin table always stays in global memory: only the cull reads it, once per unit.
+    const unsigned gm = p.grid_mode;  // 0: no grid, 1: grid resident in LDS (LDS-table kernel), 2: grid read from global memory (streamed kernel)
+    const DevGrid& grid = sc.grid;
+    const unsigned grid_words = gm == 1 ? grid.n_cells + ((grid.n_items + 1u) >> 1) : 0u;
+    uint32_t* grid_lds = reinterpret_cast<uint32_t*>(tiles + n_pad);
     const float4* tileG = STREAM ? sc.sph_cull : tiles;
-    const float4* tileP = STREAM ? p.prim_table : tiles + n_pad;
-
     if (!STREAM) {
-        for (unsigned k = threadIdx.x; k < n_pad; k += kPinThreads) {
-            tiles[k] = sc.sph_cull[k];
-            const float4 e = pinhole_entry(p, k, O);
-            float* t3 = reinterpret_cast<float*>(tiles + n_pad) + 3u * k;  // packed: 12 bytes per sphere
-            t3[0] = e.x;
-            t3[1] = e.y;
-            t3[2] = e.z;
+        const float4* src = gm == 1 ? sc.sph_exact : sc.sph_cull;
+        for (unsigned k = threadIdx.x; k < n_pad; k += kPinThreads) tiles[k] = src[k];
+        if (gm == 1) {
+            const uint32_t* items32 = reinterpret_cast<const uint32_t*>(grid.items);  // padded to whole words by the host
+            for (unsigned k = threadIdx.x; k < grid_words; k += kPinThreads) grid_lds[k] = k < grid.n_cells ? grid.cells[k] : items32[k - grid.n_cells];
         }
     }
     // triangle meshes: the top of the BVH (first nodes of the breadth-first array) sits behind the tables
-    float4* bvh_top = tiles + (STREAM ? 0u : n_pad + (n_pad >> 2) * 3u);
+    float4* bvh_top = tiles + (STREAM ? 0u : n_pad + ((grid_words + 3u) >> 2));
     if (CX) {
         const float4* src = reinterpret_cast<const float4*>(sc.bvh_nodes);
         for (unsigned k = threadIdx.x; k < p.bvh_lds_nodes * 8u; k += kPinThreads) bvh_top[k] = src[k];
@@ -115,7 +142,7 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
         usample[r] = uend[r] = usegs[r] = 0;
         ax[r] = ay[r] = az[r] = 0;
     }
-    unsigned long long my_segments = 0;
+    unsigned long long my_segments = 0, my_dbg = 0;
     bool exhausted = false, prim_done = false;
     // cull lists (wave-uniform state): entries in the list, and whether the group's cells changed since it was built
     unsigned n_cull[R];
@@ -206,8 +233,7 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (cull_stale[r]) {
-                    if (STREAM) n_cull[r] = cull_group(reinterpret_cast<const float*>(p.prim_table), n_pad, c.ci[r], c.cj[r], c.lt[r], live[r], cull_all[wave][r], lane);
-                    else n_cull[r] = cull_group((LdsF*)(tiles + n_pad), n_pad, c.ci[r], c.cj[r], c.lt[r], live[r], cull_all[wave][r], lane);
+                    n_cull[r] = cull_group(reinterpret_cast<const float*>(p.prim_table), n_pad, c.ci[r], c.cj[r], c.lt[r], live[r], cull_all[wave][r], lane);
                     cull_stale[r] = false;
                 }
                 listed &= n_cull[r] <= kCullCap;
@@ -217,7 +243,10 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
 #pragma unroll
                 for (int r = 0; r < R; ++r) scan_cull_list<R>(cull_all[wave][r], n_cull[r], r, c.ci[r], c.cj[r], c.lt[r], w, sc, head, tail, lane);
             } else {
-                scan_tile<R, 1, STREAM>(tileP, n_pad, stage, c, w, sc, head, tail, lane);
+                // more spheres in reach than a list holds (the origin sits inside a crowd): these rays take the general filter
+#pragma unroll
+                for (int r = 0; r < R; ++r) general_consts<R>(c, r, ro[r], rd[r], dot(rd[r], rd[r]), live[r], sc);
+                general_scan<R, STREAM>(gm == 1, tileG, n_pad, stage, c, w, sc, head, tail, lane);
             }
         } else {
             // ================= continuing-ray step =================
@@ -246,16 +275,28 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 w.stash[3][slot] = d.x; w.stash[4][slot] = d.y; w.stash[5][slot] = d.z;
                 w.stash[6][slot] = a;
                 w.best[slot] = kNoHit;
-                const float rs = 1.0f / __builtin_sqrtf(a);
-                c.dh[r] = d * rs;
-                c.nod[r] = -dot(o, c.dh[r]);
-                const float oo = dot(o, o);
-                const float margin = kCullKappaU * (oo + sc.c2max);
-                c.s0[r] = live[r] ? (oo - margin) : __builtin_inff();
-                c.pp[r] = f3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z);
+                general_consts<R>(c, r, o, d, a, live[r], sc);
             }
             wave_lds_sync();
-            scan_tile<R, 0, STREAM>(tileG, n_pad, stage, c, w, sc, head, tail, lane);
+            // the grid serves every ray that starts within its error budget; a wave with one that does not scans the table
+            bool walk = gm != 0;
+            if (walk) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) walk &= __ballot(live[r] && !grid_admits(grid, ro[r])) == 0ull;
+            }
+            if (walk) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float a = dot(rd[r], rd[r]);
+                    if constexpr (STREAM)  // grid mode 2
+                        grid_walk<R>(grid, grid.cells, grid.items, sc.sph_exact, ro[r], rd[r], a, live[r], r * 64u, w, sc, head, tail, lane, my_dbg);
+                    else  // grid mode 1
+                        grid_walk<R>(grid, (LdsU32*)grid_lds, (LdsU16*)(grid_lds + grid.n_cells), (LdsGV4*)tiles, ro[r], rd[r], a, live[r], r * 64u, w, sc,
+                                     head, tail, lane, my_dbg);
+                }
+            } else {
+                general_scan<R, STREAM>(gm == 1, tileG, n_pad, stage, c, w, sc, head, tail, lane);
+            }
         }
 
         // ---- drain the candidate queue, resolve ----
@@ -359,7 +400,11 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
     }
 
     if (p.total_segments) {
-        unsigned long long v = my_segments;
+#ifdef RT_DBG_WALK
+        unsigned long long v = my_dbg;
+#else
+        unsigned long long v = my_segments + 0 * my_dbg;
+#endif
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         if (lane == 0 && v) atomicAdd(p.total_segments, v);
@@ -369,8 +414,21 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
 constexpr int kR = 2;
 
 inline bool stream_mode(const TraceParams& p) { return p.sc.n_sph_pad > (uint32_t)kTileSpheres; }
-inline size_t table_lds(const TraceParams& p) { return stream_mode(p) ? 0 : (size_t)p.sc.n_sph_pad * (sizeof(float4) + 3 * sizeof(float)); }
 constexpr size_t kLdsPerBlock = 80 * 1024;  // two 512-thread blocks per CU share 160 KB
+inline size_t grid_lds_bytes(const DevGrid& g) { return ((size_t)g.n_cells * 4 + ((size_t)g.n_items + 1) / 2 * 4 + 15) / 16 * 16; }
+// 0: no grid; 1: LDS-table kernel with {p, r}, cells and items in LDS; 2: streamed kernel, grid read from global memory
+inline uint32_t grid_mode_of(const TraceParams& p, size_t static_lds)
+{
+    if (!p.sc.grid.enabled || getenv("RT_HIP_NO_GRID")) return 0;
+    if (stream_mode(p)) return 2;
+    const size_t need = static_lds + (size_t)p.sc.n_sph_pad * sizeof(float4) + grid_lds_bytes(p.sc.grid) + 512;
+    return need <= kLdsPerBlock ? 1 : 0;
+}
+inline size_t table_lds(const TraceParams& p)
+{
+    if (stream_mode(p)) return 0;
+    return (size_t)p.sc.n_sph_pad * sizeof(float4) + (p.grid_mode == 1 ? grid_lds_bytes(p.sc.grid) : 0);
+}
 inline size_t dyn_lds(const TraceParams& p) { return table_lds(p) + (size_t)p.bvh_lds_nodes * sizeof(BvhNode); }
 
 // How many tree-top nodes fit beside the kernel's static LDS and the sphere tables without costing a block per CU.
@@ -417,7 +475,16 @@ size_t pinhole_secq_bytes(const TraceParams& p, int n_cu)
     return (size_t)pinhole_grid(p, n_cu) * (kPinThreads / 64) * kSecFields * kSecCap * sizeof(uint32_t);
 }
 
-size_t pinhole_table_bytes(const TraceParams& p) { return stream_mode(p) ? (size_t)p.sc.n_sph_pad * sizeof(float4) : 0; }
+uint32_t pinhole_grid_mode(const TraceParams& p)
+{
+    if (stream_mode(p)) return grid_mode_of(p, 0);
+    hipFuncAttributes fa{};
+    const void* fn = p.sc.n_cx > 0 ? (const void*)pinhole_kernel<kR, false, true> : (const void*)pinhole_kernel<kR, false, false>;
+    if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return 0;
+    return grid_mode_of(p, fa.sharedSizeBytes);
+}
+
+size_t pinhole_table_bytes(const TraceParams& p) { return (size_t)p.sc.n_sph_pad * sizeof(float4); }  // 12 of every 16 bytes used
 
 template <bool CX>
 static hipError_t launch_pinhole_t(const TraceParams& p_in, int n_cu, int device, hipStream_t stream)
@@ -429,7 +496,7 @@ static hipError_t launch_pinhole_t(const TraceParams& p_in, int n_cu, int device
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
     bool& attr_set = attr_set_dev[device];
     if (!attr_set) {
-        const int max_dyn = (int)(kTileSpheres * sizeof(float4) * 2 + kBvhLdsNodes * sizeof(BvhNode));
+        const int max_dyn = (int)kLdsPerBlock;  // sphere table + grid + tree top, bounded by grid_mode_of / bvh_lds_fit
         hipError_t e = hipFuncSetAttribute((const void*)pinhole_kernel<kR, false, CX>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)pinhole_kernel<kR, true, CX>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -437,10 +504,12 @@ static hipError_t launch_pinhole_t(const TraceParams& p_in, int n_cu, int device
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (stream_mode(p)) {
+    // the shared-origin table of this launch's generator: read by the per-wave cull only
+    if (p.sc.n_sph_pad) {
         hipLaunchKernelGGL(pinhole_table_kernel, dim3((p.sc.n_sph_pad + 255) / 256), dim3(256), 0, stream, p, p.prim_table);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    if (stream_mode(p)) {
         hipLaunchKernelGGL((pinhole_kernel<kR, true, CX>), dim3(grid), dim3(kPinThreads), dyn_lds(p), stream, p);
         return hipGetLastError();
     }
