@@ -531,6 +531,12 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
         sph_box.push_back(make_float4(0, 0, 0, 0));
         sph_obj.push_back(-1);
     }
+    std::vector<uint2> sph_mat(n_pad, make_uint2(0, 0));
+    uint32_t n_box = 0;
+    for (uint32_t k = 0; k < n_sph; ++k) {
+        sph_mat[k] = obj_mat[sph_obj[k]];
+        if (sph_box[k].w != 0.0f) ++n_box;
+    }
     float c2max_f = (float)c2max;
     if ((double)c2max_f < c2max) c2max_f = std::nextafter(c2max_f, inf);
     // uniform grid for the continuing rays of the Projector kernel (disabled for small or unsuitable scenes)
@@ -549,6 +555,7 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     up(sph_exact, &d.sph_exact);
     up(sph_box, &d.sph_box);
     up(sph_obj, &d.sph_obj);
+    up(sph_mat, &d.sph_mat);
     up(pl_pos, &d.pl_pos);
     up(pl_nrm, &d.pl_nrm);
     up(pl_obj, &d.pl_obj);
@@ -571,6 +578,7 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
         return fail_hip(e, "scene upload");
     }
     d.n_sph = n_sph;
+    d.n_box = n_box;
     d.n_sph_pad = n_pad;
     d.n_pl = (uint32_t)pl_pos.size();
     d.n_obj = (uint32_t)n_objects;

@@ -150,7 +150,9 @@ struct WaveLds {
     unsigned queue[kQueueCap];         // (sphere index << 8) | slot
 };
 
-// Confirm up to 64 queued (slot, sphere) pairs with the exact operation sequence.
+// Confirm up to 64 queued (slot, sphere) pairs with the exact operation sequence.  best[slot] collects (t bits << 32 | j):
+// scan-path entries are in object order (sph_obj increases with j), so the smallest (t, j) is the smallest (t, object).
+// sc.sph_exact may point into LDS here (the Projector kernel's grid mode keeps the table there).
 template <int R>
 __device__ __forceinline__ void confirm_batch(WaveLds<R>& w, const DevScene& sc, unsigned head, unsigned count, unsigned lane)
 {
@@ -162,13 +164,30 @@ __device__ __forceinline__ void confirm_batch(WaveLds<R>& w, const DevScene& sc,
             F3 d = f3(w.stash[3][slot], w.stash[4][slot], w.stash[5][slot]);
             float a = w.stash[6][slot];
             const float4 s = sc.sph_exact[j];
-            const float4 hb = sc.sph_box[j];  // {half extents, 1} when entry j is the bounding sphere of a rotation-0 Box, else 0
             float t;
-            const bool hit = hb.w != 0.0f ? (box_first_t(o, d, f3(s.x, s.y, s.z), f3(hb.x, hb.y, hb.z), t) && t < __builtin_inff())
-                                          : sphere_first_t(o, d, a, f3(s.x, s.y, s.z), s.w, t);
-            if (hit) atomicMin(&w.best[slot], pack_key(t, sc.sph_obj[j]));
+            bool hit;
+            if (sc.n_box) {
+                const float4 hb = sc.sph_box[j];  // {half extents, 1} when entry j is the bounding sphere of a rotation-0 Box, else 0
+                hit = hb.w != 0.0f ? (box_first_t(o, d, f3(s.x, s.y, s.z), f3(hb.x, hb.y, hb.z), t) && t < __builtin_inff())
+                                   : sphere_first_t(o, d, a, f3(s.x, s.y, s.z), s.w, t);
+            } else {
+                hit = sphere_first_t(o, d, a, f3(s.x, s.y, s.z), s.w, t);
+            }
+            if (hit) atomicMin(&w.best[slot], pack_key(t, (int32_t)j));
         }
     }
+}
+
+// best[slot] -> the (t, object) key the rest of the step works with; sj = the scan-path entry it came from (-1: none).
+// need_obj = false (wave-uniform; no planes, no complex objects, no first-hit output): nothing reads the object index, it
+// stays the entry index and the load is skipped.
+__device__ __forceinline__ unsigned long long scan_key(const DevScene& sc, unsigned long long kb, bool need_obj, int& sj)
+{
+    sj = -1;
+    if (kb == kNoHit) return kb;
+    sj = (int)(uint32_t)kb;
+    if (!need_obj) return kb;
+    return (kb & 0xffffffff00000000ull) | (uint32_t)sc.sph_obj[sj];
 }
 
 template <int R>
@@ -289,7 +308,10 @@ __device__ __forceinline__ void scan_step(const float4 (&sp)[kUnroll], unsigned 
                     float h = __builtin_fmaf(sp[u].x, c.dh[r].x, __builtin_fmaf(sp[u].y, c.dh[r].y, __builtin_fmaf(sp[u].z, c.dh[r].z, c.nod[r])));
                     float S = __builtin_fmaf(sp[u].x, c.pp[r].x, __builtin_fmaf(sp[u].y, c.pp[r].y, __builtin_fmaf(sp[u].z, c.pp[r].z, c.s0[r])));
                     float q = __builtin_fmaf(h, h, -S);
-                    pass = q >= sp[u].w;
+                    // "not below", not "at or above": a ray with a NaN component passes.  The reference's box test reports a hit at
+                    // t_min for such rays (f32::max / f32::min drop the NaN, axis_aligned_box.rs:24-29), its sphere test none; the
+                    // confirm stage reproduces both.  Dead slots (s0 = +inf) and padding (K = +inf) still fail.
+                    pass = !(q < sp[u].w);
                 } else {
                     float4 se = sc.sph_exact[jg + u];
                     F3 lo = c.o[r] - f3(se.x, se.y, se.z);
@@ -555,17 +577,20 @@ __device__ __forceinline__ unsigned cull_group(TablePtr table, unsigned n_pad, f
     return n;
 }
 
-// The primary scan of slot group r over its cull list: same expression, same threshold as affine_h4 / affine_push4.
+// The primary scan of slot group r over its cull list: same expression, same threshold as the full-table filter had
+// ("not below": NaNs pass, as in the general filter).  Two entries per trip: the broadcast reads and the FMAs of a pair do
+// not depend on each other.
 template <int R>
-__device__ __forceinline__ void scan_cull_list(const float4* list, unsigned n, int r, float ci, float cj, float lt, WaveLds<R>& w, const DevScene& sc,
-                                               unsigned& head, unsigned& tail, unsigned lane)
+__device__ __forceinline__ void scan_cull_list(const float4* list, unsigned n, int r, float ci, float cj, float lt, bool live, WaveLds<R>& w,
+                                               const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane)
 {
-    for (unsigned k = 0; k < n; ++k) {
-        const float4 e = list[k];
-        const float h = __builtin_fmaf(ci, e.y, __builtin_fmaf(cj, e.z, e.x));
-        const bool pass = __builtin_fabsf(h) >= lt;
-        const unsigned long long mask = __ballot(pass);
-        if (mask) push_candidates<R>(w, sc, mask, pass, (unsigned)r * 64u, __float_as_uint(e.w), head, tail, lane);
+    for (unsigned k = 0; k < n; k += 2) {
+        const float4 e0 = list[k], e1 = list[k + 1 < n ? k + 1 : k];
+        const float h0 = __builtin_fmaf(ci, e0.y, __builtin_fmaf(cj, e0.z, e0.x)), h1 = __builtin_fmaf(ci, e1.y, __builtin_fmaf(cj, e1.z, e1.x));
+        const bool p0 = live && !(__builtin_fabsf(h0) < lt), p1 = live && (k + 1 < n) && !(__builtin_fabsf(h1) < lt);
+        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+        if (m0) push_candidates<R>(w, sc, m0, p0, (unsigned)r * 64u, __float_as_uint(e0.w), head, tail, lane);
+        if (m1) push_candidates<R>(w, sc, m1, p1, (unsigned)r * 64u, __float_as_uint(e1.w), head, tail, lane);
     }
 }
 
@@ -604,17 +629,39 @@ struct PreHit {
     bool front;
 };
 __device__ __forceinline__ Shade shade_hit(const DevScene& sc, F3 o, F3 d, float ior, unsigned long long key, uint64_t seed,
-                                           uint64_t path_id, uint32_t bounce, const PreHit& pre)
+                                           uint64_t path_id, uint32_t bounce, const PreHit& pre, int sj)
 {
     Shade h;
     h.obj = (int32_t)(uint32_t)(key & 0xffffffffull);
     h.t = __uint_as_float((uint32_t)(key >> 32));
-    const uint2 mat = sc.obj_mat[h.obj];
-    if (pre.valid) {
+    uint2 mat;
+    if (sj >= 0) {
+        // the winner is scan-path entry sj: geometry and material by entry index (same values as the object-indexed arrays)
+        mat = sc.sph_mat[sj];
+        const float4 g = sc.sph_exact[sj];  // sphere: {p, r}; box: {p, bounding radius}
+        const F3 pos = f3(g.x, g.y, g.z);
+        const F3 lo = o - pos;
+        const F3 pl = lo + h.t * d;  // local hit point (sphere.rs:28)
+        F3 nl;
+        float4 hb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sc.n_box) hb = sc.sph_box[sj];
+        if (hb.w != 0.0f) {  // axis_aligned_box.rs:33-41: the entry normal is kept as computed, not turned against the ray
+            nl = box_face_normal(pl, f3(hb.x, hb.y, hb.z));
+            h.front = dot(d, nl) < 0.0f;
+        } else {
+            F3 outward = pl / g.w;  // (point - 0) / radius, sphere.rs:29
+            h.front = dot(d, outward) < 0.0f;
+            nl = h.front ? outward : -outward;
+        }
+        h.point = pl + pos;        // transform.rs:37 (M = T(position))
+        h.normal = normalize(nl);  // transform.rs:39-43
+    } else if (pre.valid) {
+        mat = sc.obj_mat[h.obj];
         h.point = pre.point;
         h.normal = pre.normal;
         h.front = pre.front;
     } else {
+        mat = sc.obj_mat[h.obj];
         const float4 g = sc.obj_geom[h.obj];
         const F3 pos = f3(g.x, g.y, g.z);
         const F3 lo = o - pos;

@@ -15,6 +15,10 @@
 #pragma once
 #include "rt_device.h"
 
+#ifndef RT_WALK_ITEMS
+#define RT_WALK_ITEMS 4
+#endif
+
 namespace rt {
 
 typedef __attribute__((address_space(3))) const uint32_t LdsU32;
@@ -29,11 +33,15 @@ __device__ __forceinline__ float4 grid_sphere(LdsGV4* t, unsigned j)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// rays whose origin the grid's error budget covers (rt_host_grid.h: |o - centre| <= 2 * radius)
-__device__ __forceinline__ bool grid_admits(const DevGrid& g, F3 o)
+constexpr int kWalkItems = RT_WALK_ITEMS;  // entries of a cell tested per pass of the walk
+
+// Rays the grid may serve: the origin within the error budget (rt_host_grid.h: |o - centre| <= 2 * radius) and a finite
+// direction.  A ray with a NaN component "hits" every rotation-0 box of the scene at t_min in the reference (f32::max / min
+// drop the NaN in the slab test), wherever the box is: only the table scan reproduces that.
+__device__ __forceinline__ bool grid_admits(const DevGrid& g, F3 o, F3 d)
 {
     const F3 oc = o - f3(g.centre[0], g.centre[1], g.centre[2]);
-    return dot(oc, oc) <= g.origin_r2;
+    return dot(oc, oc) <= g.origin_r2 && dot(d, d) < __builtin_inff();
 }
 
 template <int R, typename CellPtr, typename ItemPtr, typename SphPtr>
@@ -46,6 +54,7 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
     const F3 oc = o - f3(g.centre[0], g.centre[1], g.centre[2]);
     const float slack = g.slack_k * (__builtin_amdgcn_sqrtf(dot(oc, oc)) + g.radius) * rs;
     const float ia = __builtin_amdgcn_rcpf(a);
+    const float rs1 = rs * 1.001f;  // |r| * rs1 >= the half chord of any sphere of radius r in t units
 
     // entry: slab test against the grid bounds (fmax / fmin drop NaNs; directions below 1e-30 count as parallel)
     bool active = live;
@@ -88,85 +97,86 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
     float tmz = tdz < inf ? (g.lo[2] + (float)(cz + (sz > 0 ? 1 : 0)) * g.cell - o.z) * ivz : inf;
 
     float bound = inf;  // upper bound of the t that will win, from spheres already queued
-    unsigned k = 0, cnt = 0, start = 0, last = 0xffffffffu;
+    unsigned k = 0, cnt = 0, start = 0;
     bool first = true;  // the start cell's record has not been read yet
 #if RT_DBG_WALK == 4
     if (lane == 0) ++dbg;
 #endif
     while (__ballot(active)) {
-        bool pass = false;
-        unsigned j = 0;
 #if RT_DBG_WALK == 1
         if (lane == 0) ++dbg;
 #endif
-        if (active) {
 #if RT_DBG_WALK == 2
-            ++dbg;
+        if (active) ++dbg;
 #endif
-            // one entry of the current cell (if any is left) ...
-            if (k < cnt) {
-                const unsigned it = items[start + k];
-                ++k;
-                j = it & 0x7fffu;
-                if (j != last) {  // the same entry is often registered in the next cell too
-                    last = j;
-                    if (it & 0x8000u) {
-                        pass = true;  // box: the exact slab test decides
-                    } else {
-                        // sphere.rs:13-18, operation for operation as in sphere_first_t
-                        const float4 s = grid_sphere(sph, j);
+        // up to kWalkItems entries of the current cell per pass: their loads and discriminants are independent of each other
+        bool pass[kWalkItems];
+        unsigned jj[kWalkItems];
+        const unsigned rem = active ? cnt - k : 0u;
+#pragma unroll
+        for (int u = 0; u < kWalkItems; ++u) {
+            pass[u] = false;
+            jj[u] = 0;
+            if ((unsigned)u < rem) {
+                const unsigned it = items[start + k + (unsigned)u];
+                jj[u] = it & 0x7fffu;
+                if (it & 0x8000u) {
+                    pass[u] = true;  // box: the exact slab test decides
+                } else {
+                    // sphere.rs:13-18, operation for operation as in sphere_first_t
+                    const float4 s = grid_sphere(sph, jj[u]);
 #if RT_DBG_WALK == 3
-                        ++dbg;
+                    ++dbg;
 #endif
-                        const F3 lo = o - f3(s.x, s.y, s.z);
-                        const float half_b = dot(lo, d);
-                        const float c = dot(lo, lo) - s.w * s.w;
-                        const float disc = half_b * half_b - a * c;
-                        if (!(disc < 0.0f)) {
-                            pass = true;
-                            const float sq = __builtin_amdgcn_sqrtf(disc);
-                            const float e1 = (-half_b - sq) * ia;
-                            if (e1 > kTMin + slack) bound = __builtin_fminf(bound, e1 + slack);
-                            else if (e1 < kTMin - slack && disc > 1e-6f) {
-                                const float e2 = (-half_b + sq) * ia;
-                                if (e2 > kTMin + slack) bound = __builtin_fminf(bound, e2 + slack);
-                            }
-                        }
+                    const F3 lo = o - f3(s.x, s.y, s.z);
+                    const float half_b = dot(lo, d);
+                    const float c = dot(lo, lo) - s.w * s.w;
+                    const float disc = half_b * half_b - a * c;
+                    if (!(disc < 0.0f)) {
+                        pass[u] = true;
+                        // tca = the parameter of closest approach.  If it is safely beyond t_min, sphere_first_t WILL report a
+                        // hit: t1 <= tca if t1 is valid, and if it is not (t1 <= t_min) the half chord sqrt(disc) / a exceeds
+                        // tca - t_min > slack, so disc is far above 1e-6 and t2 = tca + half chord <= tca + |r| / |d| is taken.
+                        const float tca = -half_b * ia;
+                        if (tca > kTMin + slack) bound = __builtin_fminf(bound, tca + __builtin_fmaf(__builtin_fabsf(s.w), rs1, slack));
                     }
-                }
-            }
-            // ... and, once the cell is used up, the step to the next one in the same pass (a lane's pass count is the larger
-            // of its cells and its entries, not their sum)
-            if (k >= cnt) {
-                if (!first) {
-                    const float texit = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
-                    if (bound < texit - slack) {
-                        active = false;  // everything that can still win starts before texit - slack and has been seen
-                    } else {
-    #if RT_DBG_WALK == 5
-                        ++dbg;
-#endif
-                        const bool stepx = tmx <= tmy && tmx <= tmz, stepy = !stepx && tmy <= tmz, stepz = !stepx && !stepy;
-                        cx += stepx ? sx : 0;
-                        cy += stepy ? sy : 0;
-                        cz += stepz ? sz : 0;
-                        tmx += stepx ? tdx : 0.0f;
-                        tmy += stepy ? tdy : 0.0f;
-                        tmz += stepz ? tdz : 0.0f;
-                        if ((unsigned)cx >= (unsigned)dimx || (unsigned)cy >= (unsigned)dimy || (unsigned)cz >= (unsigned)dimz) active = false;
-                    }
-                }
-                first = false;
-                if (active) {
-                    const unsigned rec = cells[((unsigned)cz * (unsigned)dimy + (unsigned)cy) * (unsigned)dimx + (unsigned)cx];
-                    start = rec & 0xfffffu;
-                    cnt = rec >> 20;
-                    k = 0;
                 }
             }
         }
-        const unsigned long long mask = __ballot(pass);
-        if (mask) push_candidates<R>(w, sc, mask, pass, slot_base, j, head, tail, lane);
+        k += rem < (unsigned)kWalkItems ? rem : (unsigned)kWalkItems;
+#pragma unroll
+        for (int u = 0; u < kWalkItems; ++u) {
+            const unsigned long long mask = __ballot(pass[u]);
+            if (mask) push_candidates<R>(w, sc, mask, pass[u], slot_base, jj[u], head, tail, lane);
+        }
+        // once the cell is used up: stop, or step to the next cell and read its record
+        if (active && k >= cnt) {
+            if (!first) {
+                const float texit = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
+                if (bound < texit - slack) {
+                    active = false;  // everything that can still win starts before texit - slack and has been seen
+                } else {
+#if RT_DBG_WALK == 5
+                    ++dbg;
+#endif
+                    const bool stepx = tmx <= tmy && tmx <= tmz, stepy = !stepx && tmy <= tmz, stepz = !stepx && !stepy;
+                    cx += stepx ? sx : 0;
+                    cy += stepy ? sy : 0;
+                    cz += stepz ? sz : 0;
+                    tmx += stepx ? tdx : 0.0f;
+                    tmy += stepy ? tdy : 0.0f;
+                    tmz += stepz ? tdz : 0.0f;
+                    if ((unsigned)cx >= (unsigned)dimx || (unsigned)cy >= (unsigned)dimy || (unsigned)cz >= (unsigned)dimz) active = false;
+                }
+            }
+            first = false;
+            if (active) {
+                const unsigned rec = cells[((unsigned)cz * (unsigned)dimy + (unsigned)cy) * (unsigned)dimx + (unsigned)cx];
+                start = rec & 0xfffffu;
+                cnt = rec >> 20;
+                k = 0;
+            }
+        }
     }
 }
 

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <limits>
 #include <vector>
 
@@ -54,7 +55,8 @@ inline GridHost build_grid(const std::vector<float4>& sph_exact, const std::vect
     double cmax = 0.0;
     for (int a = 0; a < 3; ++a) cmax = std::max(cmax, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
     const double D = 3.0 * radius0 * 1.01;
-    const double E = 3e-3 * D;
+    double E = 3e-3 * D;
+    if (const char* e = getenv("RT_HIP_GRID_E_MULT")) E *= atof(e);  // EXPLORATION ONLY (unsafe below 1)
     if (!(E > 64.0 * 0x1p-24 * (cmax + 3.0 * radius0))) return out;  // scene far from the coordinate origin relative to its size
     for (int a = 0; a < 3; ++a) {
         lo[a] -= 2.0 * E;
@@ -66,6 +68,7 @@ inline GridHost build_grid(const std::vector<float4>& sph_exact, const std::vect
         vol *= ext[a];
     }
     double cs = std::cbrt(vol / (double)n);
+    if (const char* e = getenv("RT_HIP_GRID_CELL_MULT")) cs *= atof(e);  // exploration
     // every cell at least as wide as the typical inflated sphere box would make a sphere span 8+ cells: keep cells >= 2 E
     cs = std::max(cs, 2.0 * E);
     uint32_t dim[3];

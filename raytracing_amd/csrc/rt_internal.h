@@ -72,6 +72,7 @@ struct DevScene {
     const float4* sph_exact;  // [n_sph_pad] {px, py, pz, r}; for a rotation-0 Box: its centre and bounding radius
     const float4* sph_box;    // [n_sph_pad] {half extents, 1} for such a Box, zero for spheres
     const int32_t* sph_obj;   // [n_sph_pad] object-list index of sphere j (increasing in j)
+    const uint2* sph_mat;     // [n_sph_pad] obj_mat of sphere j's object (shading a scan-path hit needs no object-indexed load)
     const float4* pl_pos;     // [n_pl] {px, py, pz, 0}
     const float4* pl_nrm;     // [n_pl] {nx, ny, nz, 0} (not normalised, as configured)
     const int32_t* pl_obj;    // [n_pl]
@@ -87,6 +88,7 @@ struct DevScene {
     uint32_t n_cx;
     uint32_t n_bvh_nodes;  // entries of bvh_nodes
     uint32_t n_sph, n_sph_pad, n_pl, n_obj;
+    uint32_t n_box;  // scan-path entries that are boxes (0: sph_box is never read)
     float c2max;  // >= max_j (|p_j|^2 + r_j^2), rounded up: magnitude bound used by the cull margin
     DevGrid grid;
 };

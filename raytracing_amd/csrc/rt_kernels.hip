@@ -165,9 +165,10 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
         for (int r = 0; r < R; ++r) {
             if (!s[r].live) continue;
             const unsigned slot = r * 64 + lane;
-            unsigned long long key = w.best[slot];
+            int sj;
+            const unsigned long long kscan = scan_key(sc, w.best[slot], true, sj);
             const F3 o = s[r].o, d = s[r].d;
-            key = planes_min_key(sc, o, d, key);
+            unsigned long long key = planes_min_key(sc, o, d, kscan);
             PreHit pre;
             pre.valid = false;
             if (CX) {
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             F3 value = f3(0, 0, 0);
             RtBounceRecord rec;
             if (key != kNoHit) {
-                const Shade sh = shade_hit(sc, o, d, s[r].ior, key, p.seed, path_id, b, pre);
+                const Shade sh = shade_hit(sc, o, d, s[r].ior, key, p.seed, path_id, b, pre, key == kscan ? sj : -1);
                 const int32_t obj = sh.obj;
                 const float t = sh.t;
                 const F3 point = sh.point, normal = sh.normal, dn = sh.dn;

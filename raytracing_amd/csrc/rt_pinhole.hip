@@ -18,6 +18,16 @@
 namespace rt {
 namespace {
 
+// In-kernel stopwatch for one region per build (-DRT_DBG_TIME=n, measurement builds only): lane 0 of every wave adds the
+// s_memtime deltas of region n to a sum that the kernel returns in place of the segment total (tools/time_frame.py prints it).
+#ifdef RT_DBG_TIME
+#define RT_T0(n) if (RT_DBG_TIME == n) t_region = __builtin_readcyclecounter();
+#define RT_T1(n) if (RT_DBG_TIME == n && lane == 0) my_dbg += __builtin_readcyclecounter() - t_region;
+#else
+#define RT_T0(n)
+#define RT_T1(n)
+#endif
+
 
 constexpr int kPinThreads = 512;  // 8 waves share the two LDS tables; 2 blocks per CU = 4 waves per SIMD
 
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
     const unsigned wave = threadIdx.x >> 6;
     WaveLds<R>& w = wl[wave];
     float4* stage = stage_all + (STREAM ? wave * 128 : 0);
-    const DevScene& sc = p.sc;
+    DevScene sc = p.sc;
     const unsigned n_pad = sc.n_sph_pad;
     const F3 O = f3(p.gen.a[0], p.gen.a[1], p.gen.a[2]);
     // LDS tables (not streamed): grid mode 1 keeps {p, r} of every sphere, the grid's cells and its item lists; otherwise the
@@ -125,6 +135,9 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
         const float4* src = reinterpret_cast<const float4*>(sc.bvh_nodes);
         for (unsigned k = threadIdx.x; k < p.bvh_lds_nodes * 8u; k += kPinThreads) bvh_top[k] = src[k];
     }
+    if (!STREAM && gm == 1) sc.sph_exact = tiles;  // confirm and shading read {p, r} from the LDS copy
+    // the object index of a scan-path hit is only looked up when something reads it
+    const bool need_obj = CX || sc.n_pl != 0 || p.first_id != nullptr;
     const BvhLds top{(LdsF4*)bvh_top, CX ? p.bvh_lds_nodes : 0u};
     if (!STREAM || CX) __syncthreads();
 
@@ -158,6 +171,11 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
     for (;;) {
         const bool do_sec = sec_count >= 64u * R || (prim_done && sec_count > 0);
         if (!do_sec && prim_done) break;
+        unsigned long long t_region = 0;
+        (void)t_region;
+        RT_T0(1)  // region 1: the whole step
+        RT_T0(2)  // region 2: set-up of a primary step
+        RT_T0(3)  // region 3: set-up of a continuing step (ring loads)
 
         ScanConsts<R> c;
         F3 ro[R], rd[R];
@@ -228,6 +246,8 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 c.lt[r] = live[r] ? __builtin_sqrtf(dot(dv, dv)) * (1.0f - 0x1p-20f) : __builtin_nanf("");  // NaN: dead slots never pass
             }
             wave_lds_sync();
+            if (true) { RT_T1(2) }
+            RT_T0(4)  // region 4: cull lists and the primary scan over them
             // groups whose cells changed rebuild their list (once per unit_samples steps when the units are of equal length)
             bool listed = true;
 #pragma unroll
@@ -241,13 +261,14 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
             if (listed) {
                 wave_lds_sync();
 #pragma unroll
-                for (int r = 0; r < R; ++r) scan_cull_list<R>(cull_all[wave][r], n_cull[r], r, c.ci[r], c.cj[r], c.lt[r], w, sc, head, tail, lane);
+                for (int r = 0; r < R; ++r) scan_cull_list<R>(cull_all[wave][r], n_cull[r], r, c.ci[r], c.cj[r], c.lt[r], live[r], w, sc, head, tail, lane);
             } else {
                 // more spheres in reach than a list holds (the origin sits inside a crowd): these rays take the general filter
 #pragma unroll
                 for (int r = 0; r < R; ++r) general_consts<R>(c, r, ro[r], rd[r], dot(rd[r], rd[r]), live[r], sc);
                 general_scan<R, STREAM>(gm == 1, tileG, n_pad, stage, c, w, sc, head, tail, lane);
             }
+            RT_T1(4)
         } else {
             // ================= continuing-ray step =================
             const unsigned n_pop = sec_count < 64u * R ? sec_count : 64u * R;
@@ -278,11 +299,13 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 general_consts<R>(c, r, o, d, a, live[r], sc);
             }
             wave_lds_sync();
+            if (true) { RT_T1(3) }
+            RT_T0(5)  // region 5: grid walk / table scan of the continuing rays
             // the grid serves every ray that starts within its error budget; a wave with one that does not scans the table
             bool walk = gm != 0;
             if (walk) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) walk &= __ballot(live[r] && !grid_admits(grid, ro[r])) == 0ull;
+                for (int r = 0; r < R; ++r) walk &= __ballot(live[r] && !grid_admits(grid, ro[r], rd[r])) == 0ull;
             }
             if (walk) {
 #pragma unroll
@@ -299,10 +322,15 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
             }
         }
 
+        if (do_sec) { RT_T1(5) }
         // ---- drain the candidate queue, resolve ----
+        RT_T0(6)  // region 6: last confirm batch
         wave_lds_sync();
         if (tail != head) confirm_batch<R>(w, sc, head, tail - head, lane);
         wave_lds_sync();
+        RT_T1(6)
+        RT_T0(7)  // regions 7 / 8: resolve, shade, accumulate, ring push of a primary / continuing step
+        RT_T0(8)
 
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -313,7 +341,9 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
             h.o_next = ro[r]; h.dn = rd[r]; h.ior = rior[r];
             if (live[r]) {
                 const unsigned slot = r * 64 + lane;
-                unsigned long long key = planes_min_key(sc, ro[r], rd[r], w.best[slot]);
+                int sj;
+                const unsigned long long kscan = scan_key(sc, w.best[slot], need_obj, sj);
+                unsigned long long key = planes_min_key(sc, ro[r], rd[r], kscan);
                 PreHit pre;
                 pre.valid = false;
                 if (CX) {
@@ -332,7 +362,7 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 bool ended = false;
                 F3 value = f3(0.f, 0.f, 0.f);
                 if (key != kNoHit) {
-                    h = shade_hit(sc, ro[r], rd[r], rior[r], key, p.seed, path_id, b, pre);
+                    h = shade_hit(sc, ro[r], rd[r], rior[r], key, p.seed, path_id, b, pre, key == kscan ? sj : -1);
                     if (b == 0 && rsample[r] == 0) {
                         if (p.first_id) p.first_id[rm[r]] = h.obj;
                         if (p.first_t) p.first_t[rm[r]] = h.t;
@@ -396,11 +426,13 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 sec_count += (unsigned)__builtin_popcountll(pm);
             }
         }
+        if (!do_sec) { RT_T1(7) } else { RT_T1(8) }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        RT_T1(1)
     }
 
     if (p.total_segments) {
-#ifdef RT_DBG_WALK
+#if defined(RT_DBG_WALK) || defined(RT_DBG_TIME)
         unsigned long long v = my_dbg;
 #else
         unsigned long long v = my_segments + 0 * my_dbg;

@@ -834,6 +834,37 @@ def test_bench_sharded_path_and_stored_checksums(engine):
         assert sharding.frame_checksum(img) == int(stored[key], 16) and segs == one.segments()
 
 
+@pytest.mark.parametrize("n_extra", [20, 400, 1200])
+def test_nan_rays_from_box_interiors_hit_boxes_as_in_the_reference(engine, n_extra):
+    """A ray that starts inside a rotation-0 box "enters" it at t_min with a zero normal (axis_aligned_box.rs:33-41, 70-95), so its
+    scattered ray is NaN; the reference's slab test then drops the NaNs (f32::max / f32::min, axis_aligned_box.rs:24-29) and reports
+    a hit at t_min on EVERY such box, wherever it is, until the bounce budget ends.  The conservative filters, the cull list and the
+    grid walk must not lose those rays (they once did: a NaN fails every ">=").  Projector inside a glass box, no rotated box in
+    front of the list to mask the effect; table scan (few objects), LDS-resident grid, streamed tables with the grid in memory."""
+    from raytracing_amd.engine import shape_object
+
+    rng = np.random.default_rng(31 + n_extra)
+    objs = [shape_object(abi.RT_SHAPE_BOX, (6.0, 5.0, 7.0), (0.2, -0.1, 0.3), abi.RT_MAT_GLASS, 1.5)]
+    kinds = [abi.RT_MAT_GLASS, abi.RT_MAT_MIRROR, abi.RT_MAT_HALF_MIRROR]
+    for k in range(n_extra):
+        pos = rng.uniform(-40.0, 40.0, 3) + np.array([0.0, 0.0, 30.0])
+        if k % 4 == 0:
+            objs.append(shape_object(abi.RT_SHAPE_BOX, tuple(rng.uniform(0.5, 4.0, 3)), tuple(pos), kinds[k % 3], [1.5, 0.0, 0.5][k % 3]))
+        else:
+            objs.append(sphere(tuple(pos), float(rng.uniform(0.4, 2.5)), kinds[k % 3], [1.5, 0.0, 0.5][k % 3]))
+    objs = np.array(objs, dtype=abi.OBJECT_DTYPE)
+    st = SimulationSettingsConfig(80.0, 5)
+    sc, osc = engine.Scene(objs), ob.OracleScene(objs)
+    for O in ((0.0, 0.0, 0.0), (0.0, 0.0, -20.0)):  # inside box 0; outside, looking through it
+        gen = projector(O, (-30.0, -22.0, 40.0), (60.0, 0.0, 0.0), (0.0, 44.0, 0.0), 48, 36)
+        got = sc.render(gen, 3, st, seed=6)
+        want = osc.render(gen, 3, 80.0, 5, seed=6, threads=8)
+        for a, b in zip(got[:4], want[:4]):
+            assert same(a, b)
+        assert got[4] == want[4]
+    assert got[4] > 48 * 36 * 3 * 2  # paths do go on after the first box hit
+
+
 def test_object_grid_of_boxes_rides_the_scan_path(engine):
     """scene_config.rs:25-49 lets an ObjectGrid stamp any shape thousands of times.  Rotation-0 boxes (axis_aligned_box.rs:12-95
     inside a translation-only Transform) take the wave-parallel scan behind their bounding spheres; records, polylines and
