@@ -26,8 +26,8 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_TEST = 17  # algorithmic reject-path cost of one ray-sphere test (sphere.rs:13-17)
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (packed FMA) at 2.4 GHz
-# FMA instructions the filter EXECUTES per ray-sphere test: primary (shared-origin) rays 2, continuing rays 7
-FMA_PER_PRIMARY_TEST, FMA_PER_CONTINUING_TEST = 2, 7
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave-level VALU instruction per 4 cycles per SIMD, 2.4 GHz (MI355X_MICROARCH.md)
+PEAK_VALU_GINST = 256 * 4 * 2.4 / 4.0
 CHECKSUMS = os.path.join(ROOT, "tests", "golden", "frame_checksums.json")
 PMC = os.path.join(ROOT, "profiles", "pmc_constants.json")
 
@@ -186,11 +186,6 @@ def main():
         value = segs_all * args.steps / elapsed_max / 1e6
         launches = len(frame.launches)
         kernel_ms = render_ms / launches  # average duration of one launch of the dominant kernel (finalize + memsets: < 0.5 %)
-        prim_local = frame.count * spp  # primary segments of this rank's cells; the rest are continuing rays
-        cont_local = segs_local - prim_local
-        n_pad = (n_sph + 3) // 4 * 4 if n_sph <= 1024 else (n_sph + 63) // 64 * 64
-        fma_flop = 2.0 * n_pad * (FMA_PER_PRIMARY_TEST * prim_local + FMA_PER_CONTINUING_TEST * cont_local)
-        achieved = fma_flop / (render_ms * 1e-3) / 1e12
         algorithmic = segs_local * FLOP_PER_TEST * n_sph / (render_ms * 1e-3) / 1e12
         pmc = {}
         if os.path.exists(PMC):
@@ -198,31 +193,37 @@ def main():
                 pmc = json.load(open(PMC)).get(name, {})
             except Exception:
                 pmc = {}
-        traffic = pmc.get("hbm_bytes_per_launch")
+        traffic = pmc.get("hbm_bytes_per_frame")
         clk = pmc.get("clock_ghz")
+        share = frame.count / n_cells  # this rank's part of the frame (cells are dealt round-robin: a uniform sample of the image)
+        insts = pmc.get("valu_insts_per_frame")
+        achieved = None if insts is None else insts * share / (render_ms * 1e-3) / 1e9
         roof = {
-            "bound": "valu_fp32",
+            "bound": "valu_issue",
             "kernel": "pinhole_kernel<2, %s, false> (Projector render loop)" % ("false" if n_sph <= 1024 else "true"),
             "achieved": achieved,
-            "peak": PEAK_FP32_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_TFLOPS,
-            "traffic": traffic,
+            "peak": PEAK_VALU_GINST,
+            "unit": "Ginst/s",
+            "frac": None if achieved is None else achieved / PEAK_VALU_GINST,
+            "traffic": None if traffic is None else traffic * share / launches,
             "kernel_ms": kernel_ms,
             "launches_per_step": launches,
-            "definition": "EXECUTED filter work: 2 FLOP x (2 FMA per primary test + 7 FMA per continuing-ray test) x padded spheres x segments "
-                          "of this rank / its kernel time (HIP events on the launch stream), over the packed-FMA FP32 vector peak; compares, "
-                          "v_max3, LDS broadcasts and the exact confirm stage are not counted as FLOP",
-            "frac_at_sustained_clock": None if not clk else achieved / (PEAK_FP32_TFLOPS * clk / 2.4),
+            "definition": "EXECUTED work: wave-level VALU instructions of this rank's share of the frame (SQ_INSTS_VALU of the committed "
+                          "rocprofv3 pass of this kernel and workload, profiles/pmc_constants.json) / its kernel time (HIP events on the "
+                          "launch stream), over the VALU issue peak of the chip: 1,024 SIMDs x one wave instruction per 4 cycles at 2.4 GHz. "
+                          "The kernel no longer scans the sphere table: primary rays test a per-wave cull list, continuing rays walk a "
+                          "uniform grid, so FLOP per sphere test is not the executed work any more (algorithmic_equiv keeps that figure).",
+            "frac_at_sustained_clock": None if not clk or achieved is None else achieved / (PEAK_VALU_GINST * clk / 2.4),
             "sustained_clock_ghz": clk,
             "valu_issue_util": pmc.get("valu_issue_util"),
             "valu_lane_util": pmc.get("valu_lane_util"),
             "pmc_source": pmc.get("source"),
-            "algorithmic_equiv": {"flop_per_test": FLOP_PER_TEST, "achieved": algorithmic, "frac": algorithmic / PEAK_FP32_TFLOPS,
-                                  "note": "SURVEY.md §8d accounting (17 FLOP per test the reference's formulation would spend); can exceed 1 because "
-                                          "the filter executes fewer operations than that formulation"},
-            "hbm": None if traffic is None else {"achieved": traffic / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                                  "frac": traffic / (kernel_ms * 1e-3) / 1e9 / 8000.0},
+            "algorithmic_equiv": {"flop_per_test": FLOP_PER_TEST, "achieved": algorithmic, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": algorithmic / PEAK_FP32_TFLOPS,
+                                  "note": "SURVEY.md §8d accounting: 17 FLOP for every (segment, sphere) pair the reference's linear scan would "
+                                          "test, over the FP32 vector peak; far above 1 because almost none of those tests is executed"},
+            "hbm": None if traffic is None else {"achieved": traffic * share / (render_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                                  "frac": traffic * share / (render_ms * 1e-3) / 1e9 / 8000.0},
         }
         full = "C2" if name == "c2" else "C4"
         out = {
@@ -247,7 +248,7 @@ def main():
                 # "1/8 GPU" read both ways: value is per whole MI355X (one of a node's eight) at N=1; one XCD's share is value/8/N
                 "mrays_per_s_per_gpu": value / world,
                 "mrays_per_s_per_xcd": value / world / 8,
-                "pct_of_fp32_valu_peak": 100.0 * achieved / PEAK_FP32_TFLOPS,
+                "pct_of_fp32_valu_peak": None if achieved is None else 100.0 * achieved / PEAK_VALU_GINST,
             },
             "roofline": roof,
         }

@@ -176,7 +176,9 @@ int g_scan_mode = 0;
 bool use_pinhole(const rt::TraceParams& p)
 {
     if (getenv("RT_HIP_NO_PINHOLE")) return false;  // tuning / A-B knob
-    return !p.rays && p.gen.kind == RT_GEN_PROJECTOR && p.scan_mode == 0 && p.fb_q != nullptr;
+    // cell indices must be exact in f32 (the shared-origin filter and its cull work on them as floats)
+    return !p.rays && p.gen.kind == RT_GEN_PROJECTOR && p.scan_mode == 0 && p.fb_q != nullptr && p.gen.count_u <= (1u << 24) &&
+           p.gen.count_v <= (1u << 24);
 }
 
 // Rounding budget of the shared-origin filter's affine numerator: rho = (3G + 7M) / d_min, with

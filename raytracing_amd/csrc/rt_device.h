@@ -273,14 +273,14 @@ __device__ __forceinline__ F3 sky(F3 d)
 // ---------------------------------------------------------------------------------------------------
 // The scan step: every live slot of the wave against `count` spheres of an LDS tile.
 //   FLAVOR 0  general ray:   pass iff fma(h,h,-S) >= K,  h = p.dh + nod,  S = p.pp + s0        (8 VALU / test)
-//   FLAVOR 1  pinhole ray:   pass iff |A' + i B' + j C'| >= L   (tile holds {A, B, C} / sK; L ~ |target - O|)   (3 VALU / test)
+//   (the shared-origin filter |A' + i B' + j C'| >= L of Projector rays runs on per-wave cull lists: cull_group / scan_cull_list)
 //   FLAVOR 2  exact filter:  pass iff the reference's own discriminant is not < 0 (sphere.rs:13-18)
 // Survivors go to the wave's candidate queue and are confirmed with the exact sequence.
 // ---------------------------------------------------------------------------------------------------
 template <int R>
 struct ScanConsts {
     F3 dh[R];      // unit direction
-    float ci[R], cj[R], lt[R];  // FLAVOR 1: cell indices i, j and a lower bound of |target - O| (NaN for dead slots)
+    float ci[R], cj[R], lt[R];  // shared-origin filter: cell indices i, j and a lower bound of |target - O|
     float nod[R];  // -(o . dh)
     F3 pp[R];      // -2 o
     float s0[R];   // |o|^2 - margin  (+inf for dead slots)
@@ -297,7 +297,7 @@ __device__ __forceinline__ void scan_step(const float4 (&sp)[kUnroll], unsigned 
     unsigned long long mk[kUnroll][R];
     bool ps[kUnroll][R];
     unsigned long long any = 0;
-    static_assert(FLAVOR != 1, "the shared-origin filter runs in scan_step_affine");
+    static_assert(FLAVOR == 0 || FLAVOR == 2, "general filter or exact filter");
     {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
@@ -337,93 +337,6 @@ __device__ __forceinline__ void scan_step(const float4 (&sp)[kUnroll], unsigned 
     }
 }
 
-// FLAVOR 1 on the packed table: the 12 floats of four spheres arrive as six aligned register pairs, and every table
-// scalar is fed to v_pk_fma_f32 as "low half twice" or "high half twice" of the pair it sits in (op_sel), never copied.
-typedef float RtV2f __attribute__((ext_vector_type(2)));
-typedef float RtV4f __attribute__((ext_vector_type(4)));
-
-// hv[u] = {A + i B + j C of sphere u for slot 0, for slot 1}: eight v_pk_fma_f32 for four spheres x two rays.
-template <int R>
-__device__ __forceinline__ void affine_h4(RtV4f a, RtV4f b, RtV4f d, const ScanConsts<R>& c, RtV2f (&hv)[4])
-{
-    static_assert(R == 2 && kUnroll == 4, "two slots per lane, four spheres per step");
-    const RtV2f cj2 = {c.cj[0], c.cj[1]}, ci2 = {c.ci[0], c.ci[1]};
-    RtV2f p0 = a.xy, p1 = a.zw, p2 = b.xy, p3 = b.zw, p4 = d.xy, p5 = d.zw;
-    // opaque to the optimiser from here on: a splat of the 4th element of a 16-byte tuple is not folded into op_sel, a
-    // splat of the 2nd element of a register pair is
-    asm("" : "+v"(p1));
-    asm("" : "+v"(p3));
-    asm("" : "+v"(p5));
-#define RT_LO(p) __builtin_shufflevector(p, p, 0, 0)
-#define RT_HI(p) __builtin_shufflevector(p, p, 1, 1)
-    // sphere 0: A = p0.lo, B = p0.hi, C = p1.lo | 1: p1.hi, p2.lo, p2.hi | 2: p3.lo, p3.hi, p4.lo | 3: p4.hi, p5.lo, p5.hi
-    hv[0] = __builtin_elementwise_fma(cj2, RT_LO(p1), RT_LO(p0));
-    hv[1] = __builtin_elementwise_fma(cj2, RT_HI(p2), RT_HI(p1));
-    hv[2] = __builtin_elementwise_fma(cj2, RT_LO(p4), RT_LO(p3));
-    hv[3] = __builtin_elementwise_fma(cj2, RT_HI(p5), RT_HI(p4));
-    hv[0] = __builtin_elementwise_fma(ci2, RT_HI(p0), hv[0]);
-    hv[1] = __builtin_elementwise_fma(ci2, RT_LO(p2), hv[1]);
-    hv[2] = __builtin_elementwise_fma(ci2, RT_HI(p3), hv[2]);
-    hv[3] = __builtin_elementwise_fma(ci2, RT_LO(p5), hv[3]);
-#undef RT_LO
-#undef RT_HI
-}
-
-// slow path of the shared-origin scan: individual masks of four spheres, survivors to the candidate ring
-template <int R>
-__device__ __forceinline__ void affine_push4(const RtV2f (&hv)[4], unsigned jg, const ScanConsts<R>& c, WaveLds<R>& w, const DevScene& sc,
-                                             unsigned& head, unsigned& tail, unsigned lane)
-{
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const bool p0 = __builtin_fabsf(hv[u].x) >= c.lt[0], p1 = __builtin_fabsf(hv[u].y) >= c.lt[1];
-        const unsigned long long k0 = __ballot(p0), k1 = __ballot(p1);
-        if (k0) push_candidates<R>(w, sc, k0, p0, 0, jg + u, head, tail, lane);
-        if (k1) push_candidates<R>(w, sc, k1, p1, 64, jg + u, head, tail, lane);
-    }
-}
-
-__device__ __forceinline__ float max3_abs(float a, float b, float c)
-{
-    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c));
-}
-
-// The threshold is per ray, not per sphere, so "does any sphere of the group pass" is a v_max3 chain and two compares per
-// slot instead of one compare per sphere; the individual masks are only built when something did pass.
-template <int R>
-__device__ __forceinline__ void scan_step_affine(RtV4f a, RtV4f b, RtV4f d, unsigned jg, const ScanConsts<R>& c, WaveLds<R>& w,
-                                                 const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane)
-{
-    RtV2f hv[4];
-    affine_h4<R>(a, b, d, c, hv);
-    const float m0 = max3_abs(hv[0].x, hv[1].x, hv[2].x), m1 = max3_abs(hv[0].y, hv[1].y, hv[2].y);
-    const bool any0 = (m0 >= c.lt[0]) | (__builtin_fabsf(hv[3].x) >= c.lt[0]);
-    const bool any1 = (m1 >= c.lt[1]) | (__builtin_fabsf(hv[3].y) >= c.lt[1]);
-    if (__ballot(any0 | any1)) affine_push4<R>(hv, jg, c, w, sc, head, tail, lane);
-}
-
-// Eight spheres per decision: three v_max3 and two compares per slot.
-template <int R>
-__device__ __forceinline__ void scan_step_affine8(RtV4f a0, RtV4f b0, RtV4f d0, RtV4f a1, RtV4f b1, RtV4f d1, unsigned jg,
-                                                  const ScanConsts<R>& c, WaveLds<R>& w, const DevScene& sc, unsigned& head,
-                                                  unsigned& tail, unsigned lane)
-{
-    RtV2f hA[4], hB[4];
-    affine_h4<R>(a0, b0, d0, c, hA);
-    affine_h4<R>(a1, b1, d1, c, hB);
-    float m0 = max3_abs(hA[0].x, hA[1].x, hA[2].x), m1 = max3_abs(hA[0].y, hA[1].y, hA[2].y);
-    m0 = max3_abs(m0, hA[3].x, hB[0].x);
-    m1 = max3_abs(m1, hA[3].y, hB[0].y);
-    m0 = max3_abs(m0, hB[1].x, hB[2].x);
-    m1 = max3_abs(m1, hB[1].y, hB[2].y);
-    const bool any0 = (m0 >= c.lt[0]) | (__builtin_fabsf(hB[3].x) >= c.lt[0]);
-    const bool any1 = (m1 >= c.lt[1]) | (__builtin_fabsf(hB[3].y) >= c.lt[1]);
-    if (__ballot(any0 | any1)) {
-        affine_push4<R>(hA, jg, c, w, sc, head, tail, lane);
-        affine_push4<R>(hB, jg + 4, c, w, sc, head, tail, lane);
-    }
-}
-
 // The scan over a whole sphere table.
 //   PF = false: `tile` is the block's LDS table; every step reads kUnroll spheres with wave-uniform ds_read_b128.
 //   PF = true : the table (count % 64 == 0) lives in global memory / L2 (scenes above kTileSpheres).  A wave-uniform
@@ -434,61 +347,12 @@ template <int R, int FLAVOR, bool PF>
 __device__ __forceinline__ void scan_tile(const float4* tile, unsigned count, float4* stage, const ScanConsts<R>& c,
                                           WaveLds<R>& w, const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane)
 {
-    if constexpr (!PF && FLAVOR == 1) {
-        // shared-origin table in LDS: 3 floats per sphere, packed, so kUnroll = 4 spheres are three 16-byte broadcasts
-        // (the table read, not the VALU, is what this loop would otherwise wait for)
-        static_assert(kUnroll == 4, "packed table layout assumes 4 spheres per step");
-        // volatile: the three 16-byte reads are issued as written (otherwise the compiler re-slices them into five narrower ones)
-        typedef float V4f __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(3))) const volatile V4f LdsV4;
-        LdsV4* t = (LdsV4*)tile;
-        unsigned j = 0;
-        for (; j + 2 * kUnroll <= count; j += 2 * kUnroll) {
-            LdsV4* t6 = t + (j >> 2) * 3u;
-            const V4f a0 = t6[0], b0 = t6[1], d0 = t6[2], a1 = t6[3], b1 = t6[4], d1 = t6[5];
-            scan_step_affine8<R>(a0, b0, d0, a1, b1, d1, j, c, w, sc, head, tail, lane);
-        }
-        if (j < count) {  // count is a multiple of four
-            LdsV4* t3 = t + (j >> 2) * 3u;
-            const V4f a = t3[0], b = t3[1], d = t3[2];
-            scan_step_affine<R>(a, b, d, j, c, w, sc, head, tail, lane);
-        }
-    } else if constexpr (!PF) {
+    if constexpr (!PF) {
         for (unsigned j = 0; j < count; j += kUnroll) {
             float4 sp[kUnroll];
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) sp[u] = tile[j + u];
             scan_step<R, FLAVOR>(sp, j, c, w, sc, head, tail, lane);
-        }
-    } else if constexpr (FLAVOR == 1) {
-        // streamed shared-origin table: packed 12-byte entries in global memory, one per lane per load, parked in the
-        // wave's staging buffer in the same packed form and then read exactly like the LDS-resident table
-        if (count == 0) return;
-        typedef float V4f __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(3))) const volatile V4f LdsV4;
-        const float* g = reinterpret_cast<const float*>(tile);
-        float* st = reinterpret_cast<float*>(stage);
-        float n0 = g[3u * lane], n1 = g[3u * lane + 1], n2 = g[3u * lane + 2];
-        unsigned buf = 0;
-        for (unsigned base = 0; base < count; base += 64) {
-            float* sb = st + buf * 192u;
-            sb[3u * lane] = n0;
-            sb[3u * lane + 1] = n1;
-            sb[3u * lane + 2] = n2;
-            if (base + 64 < count) {
-                const float* gn = g + 3u * (base + 64 + lane);
-                n0 = gn[0];
-                n1 = gn[1];
-                n2 = gn[2];
-            }
-            wave_lds_sync();
-            LdsV4* t = (LdsV4*)sb;
-            for (unsigned j = 0; j < 64; j += 2 * kUnroll) {
-                LdsV4* t6 = t + (j >> 2) * 3u;
-                const V4f a0 = t6[0], b0 = t6[1], d0 = t6[2], a1 = t6[3], b1 = t6[4], d1 = t6[5];
-                scan_step_affine8<R>(a0, b0, d0, a1, b1, d1, base + j, c, w, sc, head, tail, lane);
-            }
-            buf ^= 1;
         }
     } else {
         if (count == 0) return;
@@ -515,7 +379,7 @@ __device__ __forceinline__ void scan_tile(const float4* tile, unsigned count, fl
 // A sphere whose affine form cannot reach the smallest threshold of the group anywhere in the group's bounding box of cell
 // indices cannot pass for any of its rays, in any of those steps; the few that can are copied to a per-group LDS list once,
 // and the primary scan of the following steps reads that list instead of the whole table.  The per-ray test on the list is
-// the same expression as in affine_h4, so every ray sees exactly the candidates it would have seen in the full scan.
+// the expression h = fma(i, B', fma(j, C', A')), so every ray sees exactly the candidates it would have seen in the full scan.
 //
 // Bound.  h(i, j) = fl(fl(a + j c) + i b) is the value the per-ray test computes.  With T = |a| + jmax |c| + imax |b| and
 // u = 2^-24, |h(i, j) - (a + j c + i b)| <= 2.01 u T for every cell of the box, and the same holds for the centre value hc,
@@ -523,7 +387,6 @@ __device__ __forceinline__ void scan_tile(const float4* tile, unsigned count, fl
 // (three more roundings, each below u T), adds 8 u T instead of 4.02 u T and scales by 1 + 2^-20: a sphere is dropped only
 // if even the inflated bound stays below the smallest threshold.  inf entries ("always") and NaNs survive.
 // ---------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) const float LdsF;
 constexpr unsigned kCullCap = 40;  // list entries per slot group; a group that needs more falls back to the full table scan
 
 __device__ __forceinline__ float wave_min(float v)
@@ -539,10 +402,10 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
-// table: packed {A', B', C'} per sphere (LDS or global memory), n_pad entries.  Returns the number of surviving spheres;
+// table: {A', B', C', -} per sphere in global memory, n_pad entries.  Returns the number of surviving spheres;
 // list[0 .. min(n, kCullCap)) = {A', B', C', sphere index bits}.  n > kCullCap: the list is incomplete, scan the table.
-template <typename TablePtr>
-__device__ __forceinline__ unsigned cull_group(TablePtr table, unsigned n_pad, float ci, float cj, float lt, bool live, float4* list, unsigned lane)
+// Four 64-sphere rows per trip, their loads issued together: the loop is a chain of L2 round trips otherwise.
+__device__ __forceinline__ unsigned cull_group(const float4* table, unsigned n_pad, float ci, float cj, float lt, bool live, float4* list, unsigned lane)
 {
     const float inf = __builtin_inff();
     const float imin = wave_min(live ? ci : inf), imax = wave_max(live ? ci : -inf);
@@ -552,26 +415,30 @@ __device__ __forceinline__ unsigned cull_group(TablePtr table, unsigned n_pad, f
     // cell indices are integers below 2^24: sums, differences and halves are exact
     const float ic = 0.5f * (imin + imax), di = 0.5f * (imax - imin), jc = 0.5f * (jmin + jmax), dj = 0.5f * (jmax - jmin);
     unsigned n = 0;
-    for (unsigned base = 0; base < n_pad; base += 64) {
-        const unsigned k = base + lane;
-        bool pass = false;
-        float a = 0.f, b = 0.f, c = 0.f;
-        if (k < n_pad) {
-            a = table[3u * k];
-            b = table[3u * k + 1];
-            c = table[3u * k + 2];
+    constexpr int kRows = 4;
+    for (unsigned base = 0; base < n_pad; base += 64u * kRows) {
+        float4 e[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) {
+            const unsigned k = base + 64u * (unsigned)u + lane;
+            e[u] = table[k < n_pad ? k : n_pad - 1u];
+        }
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) {
+            const unsigned k = base + 64u * (unsigned)u + lane;
+            const float a = e[u].x, b = e[u].y, c = e[u].z;
             const float fa = __builtin_fabsf(a), fb = __builtin_fabsf(b), fc = __builtin_fabsf(c);
             const float hc = __builtin_fmaf(ic, b, __builtin_fmaf(jc, c, a));
             float U = __builtin_fmaf(di, fb, __builtin_fmaf(dj, fc, __builtin_fabsf(hc)));
             const float T = __builtin_fmaf(imax, fb, __builtin_fmaf(jmax, fc, fa));
             U = __builtin_fmaf(T, 0x1p-21f, U);
-            pass = !(U * (1.0f + 0x1p-20f) < lmin);
-        }
-        const unsigned long long mask = __ballot(pass);
-        if (mask) {
-            const unsigned pos = n + mbcnt64(mask);
-            if (pass && pos < kCullCap) list[pos] = make_float4(a, b, c, __uint_as_float(k));
-            n += (unsigned)__builtin_popcountll(mask);
+            const bool pass = k < n_pad && !(U * (1.0f + 0x1p-20f) < lmin);
+            const unsigned long long mask = __ballot(pass);
+            if (mask) {
+                const unsigned pos = n + mbcnt64(mask);
+                if (pass && pos < kCullCap) list[pos] = make_float4(a, b, c, __uint_as_float(k));
+                n += (unsigned)__builtin_popcountll(mask);
+            }
         }
     }
     return n;

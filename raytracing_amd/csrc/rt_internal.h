@@ -127,7 +127,7 @@ struct TraceParams {
     uint32_t* secq;     // per-wave rings of continuing rays: [grid waves][kSecFields][kSecCap] dwords
     float prim_margin;  // >= 64 u * max_j(|p_j - O|^2 + r_j^2): margin of the shared-origin filter
     float prim_rho;     // (3G + 7M) / d_min of the Projector: rounding of the affine numerator relative to |target - O|
-    float4* prim_table; // 3 floats per sphere {A, B, C} / sK (packed), rebuilt per launch; read by the per-wave cull
+    float4* prim_table; // {A, B, C, 0} / sK per sphere, rebuilt per launch; read by the per-wave cull
     uint32_t bvh_lds_nodes;  // pinhole kernel: the first this-many BvhNodes are copied into LDS (set by launch_pinhole)
     uint32_t grid_mode;      // pinhole kernel: 0 no grid, 1 grid in LDS, 2 grid in global memory (pinhole_grid_mode, set before sizing)
 };

@@ -61,17 +61,11 @@ __device__ __forceinline__ float4 pinhole_entry(const TraceParams& p, unsigned k
     return make_float4(a, b, c, 0.f);
 }
 
-// Streamed variant: the table is built once per launch in global memory.
+// The shared-origin table of a launch: built once in global memory, read by the per-wave cull (rt_device.h cull_group).
 __global__ void pinhole_table_kernel(const TraceParams p, float4* table)
 {
     const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < p.sc.n_sph_pad) {
-        const float4 e = pinhole_entry(p, k, f3(p.gen.a[0], p.gen.a[1], p.gen.a[2]));
-        float* t3 = reinterpret_cast<float*>(table) + 3u * k;  // packed: 12 bytes per sphere
-        t3[0] = e.x;
-        t3[1] = e.y;
-        t3[2] = e.z;
-    }
+    if (k < p.sc.n_sph_pad) table[k] = pinhole_entry(p, k, f3(p.gen.a[0], p.gen.a[1], p.gen.a[2]));
 }
 
 // Constants of the general filter (FLAVOR 0 of scan_step) for slot r.
@@ -173,6 +167,7 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
         if (!do_sec && prim_done) break;
         unsigned long long t_region = 0;
         (void)t_region;
+        RT_T0(11)
         RT_T0(1)  // region 1: the whole step
         RT_T0(2)  // region 2: set-up of a primary step
         RT_T0(3)  // region 3: set-up of a continuing step (ring loads)
@@ -220,6 +215,8 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 prim_done = true;
                 continue;
             }
+            if (true) { RT_T1(11) }  // region 11: unit assignment (work counter, division) of a primary step
+            RT_T0(12)                // region 12: ray set-up of a primary step
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 rm[r] = um[r];
@@ -236,6 +233,7 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 w.stash[6][slot] = a;
                 w.best[slot] = kNoHit;
                 // shared-origin filter constants: cell indices (exact in f32) and a lower bound of |target - O|
+                // (recomputed every step: parking them per unit in registers or private memory measured slower)
                 uint32_t ci, cj;
                 cell_indices(p, live[r] ? um[r] : 0u, ci, cj);
                 c.ci[r] = (float)ci;
@@ -243,17 +241,18 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 const F3 corner = f3(p.gen.corner[0], p.gen.corner[1], p.gen.corner[2]);
                 const F3 us = f3(p.gen.u_step[0], p.gen.u_step[1], p.gen.u_step[2]), vs = f3(p.gen.v_step[0], p.gen.v_step[1], p.gen.v_step[2]);
                 const F3 dv = ((corner + (c.ci[r] * us)) + (c.cj[r] * vs)) - O;  // the reference's target - origin (scene_config.rs:98-100)
-                c.lt[r] = live[r] ? __builtin_sqrtf(dot(dv, dv)) * (1.0f - 0x1p-20f) : __builtin_nanf("");  // NaN: dead slots never pass
+                c.lt[r] = live[r] ? __builtin_sqrtf(dot(dv, dv)) * (1.0f - 0x1p-20f) : __builtin_inff();  // dead slots are masked by `live`
             }
             wave_lds_sync();
             if (true) { RT_T1(2) }
+            if (true) { RT_T1(12) }
             RT_T0(4)  // region 4: cull lists and the primary scan over them
             // groups whose cells changed rebuild their list (once per unit_samples steps when the units are of equal length)
             bool listed = true;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (cull_stale[r]) {
-                    n_cull[r] = cull_group(reinterpret_cast<const float*>(p.prim_table), n_pad, c.ci[r], c.cj[r], c.lt[r], live[r], cull_all[wave][r], lane);
+                    n_cull[r] = cull_group(p.prim_table, n_pad, c.ci[r], c.cj[r], c.lt[r], live[r], cull_all[wave][r], lane);
                     cull_stale[r] = false;
                 }
                 listed &= n_cull[r] <= kCullCap;
@@ -516,7 +515,7 @@ uint32_t pinhole_grid_mode(const TraceParams& p)
     return grid_mode_of(p, fa.sharedSizeBytes);
 }
 
-size_t pinhole_table_bytes(const TraceParams& p) { return (size_t)p.sc.n_sph_pad * sizeof(float4); }  // 12 of every 16 bytes used
+size_t pinhole_table_bytes(const TraceParams& p) { return (size_t)p.sc.n_sph_pad * sizeof(float4); }
 
 template <bool CX>
 static hipError_t launch_pinhole_t(const TraceParams& p_in, int n_cu, int device, hipStream_t stream)

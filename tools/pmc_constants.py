@@ -1,7 +1,7 @@
 """Derives the PMC constants bench.py reports (roofline.traffic, valu_issue_util, valu_lane_util, sustained clock) from a
 committed rocprofv3 summary (tools/rocpd_summary.py text) and merges them into profiles/pmc_constants.json.
 
-usage: python tools/pmc_constants.py NAME SUMMARY.txt [KERNEL_SUBSTRING]
+usage: python tools/pmc_constants.py NAME SUMMARY.txt [KERNEL_SUBSTRING] [LAUNCHES_PER_FRAME]
   valu_issue_util = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * SQ_BUSY_CYCLES / 32 SEs)      (quad-cycles -> cycles; busy cycles per SE)
   valu_lane_util  = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
   clock_ghz       = SQ_BUSY_CYCLES / 32 / (kernel time of the same pass)                  (cross-check: GRBM_GUI_ACTIVE / 8 / time)
@@ -15,6 +15,7 @@ import sys
 
 name, path = sys.argv[1], sys.argv[2]
 kernel = sys.argv[3] if len(sys.argv) > 3 else "pinhole_kernel"
+launches_per_frame = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # C2: one launch per frame; C4 on one GPU: four launches of 2^21 cells
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 counters, disp, passes = {}, {}, []
 cur = None
@@ -52,6 +53,11 @@ for p in passes:
         out["atomic_requests_per_launch"] = c["TCC_EA0_ATOMIC_sum"][0] / c["TCC_EA0_ATOMIC_sum"][1]
 if "write_bytes_per_launch" in out and "fetch_bytes_per_launch" in out:
     out["hbm_bytes_per_launch"] = out["write_bytes_per_launch"] + out["fetch_bytes_per_launch"]
+if out.get("valu_insts_per_launch") is not None:
+    out["valu_insts_per_frame"] = out["valu_insts_per_launch"] * launches_per_frame
+if "hbm_bytes_per_launch" in out:
+    out["hbm_bytes_per_frame"] = out["hbm_bytes_per_launch"] * launches_per_frame
+out["launches_per_frame"] = launches_per_frame
 dst = os.path.join(ROOT, "profiles", "pmc_constants.json")
 allc = json.load(open(dst)) if os.path.exists(dst) else {}
 allc[name] = out
