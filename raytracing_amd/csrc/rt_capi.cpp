@@ -534,10 +534,10 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
         sph_obj.push_back(-1);
     }
     std::vector<uint2> sph_mat(n_pad, make_uint2(0, 0));
-    uint32_t n_box = 0;
+    uint32_t n_box = 0, first_box = 0;
     for (uint32_t k = 0; k < n_sph; ++k) {
         sph_mat[k] = obj_mat[sph_obj[k]];
-        if (sph_box[k].w != 0.0f) ++n_box;
+        if (sph_box[k].w != 0.0f && n_box++ == 0) first_box = k;
     }
     float c2max_f = (float)c2max;
     if ((double)c2max_f < c2max) c2max_f = std::nextafter(c2max_f, inf);
@@ -581,6 +581,7 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     }
     d.n_sph = n_sph;
     d.n_box = n_box;
+    d.first_box = first_box;
     d.n_sph_pad = n_pad;
     d.n_pl = (uint32_t)pl_pos.size();
     d.n_obj = (uint32_t)n_objects;

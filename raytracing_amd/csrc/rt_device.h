@@ -178,6 +178,19 @@ __device__ __forceinline__ void confirm_batch(WaveLds<R>& w, const DevScene& sc,
     }
 }
 
+// A ray whose direction is NaN in every component (what leaves a hit with a zero normal: a box entered from inside) fails the
+// sphere test everywhere and "enters" EVERY rotation-0 box at t_min: f32::max / f32::min drop the NaN bounds of all three slabs
+// (axis_aligned_box.rs:24-29).  All boxes tie at t_min, so the first one in object order wins: such a ray queues that single
+// entry and takes no part in the scan (confirm_batch still runs the exact test on it).
+__device__ __forceinline__ bool nan_ray(F3 d) { return d.x != d.x && d.y != d.y && d.z != d.z; }
+template <int R>
+__device__ __forceinline__ void push_nan_rays(WaveLds<R>& w, const DevScene& sc, bool is_nan, unsigned slot_base, unsigned& head, unsigned& tail,
+                                              unsigned lane)
+{
+    const unsigned long long mask = __ballot(is_nan);
+    if (mask && sc.n_box) push_candidates<R>(w, sc, mask, is_nan, slot_base, sc.first_box, head, tail, lane);
+}
+
 // best[slot] -> the (t, object) key the rest of the step works with; sj = the scan-path entry it came from (-1: none).
 // need_obj = false (wave-uniform; no planes, no complex objects, no first-hit output): nothing reads the object index, it
 // stays the entry index and the load is skipped.

@@ -134,11 +134,12 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
                     const float disc = half_b * half_b - a * c;
                     if (!(disc < 0.0f)) {
                         pass[u] = true;
-                        // tca = the parameter of closest approach.  If it is safely beyond t_min, sphere_first_t WILL report a
-                        // hit: t1 <= tca if t1 is valid, and if it is not (t1 <= t_min) the half chord sqrt(disc) / a exceeds
-                        // tca - t_min > slack, so disc is far above 1e-6 and t2 = tca + half chord <= tca + |r| / |d| is taken.
+                        // tca = the parameter of closest approach.  If it is safely beyond t_min and the discriminant above the
+                        // reference's 1e-6 (sphere.rs:52; an absolute number, so it has to be asked for: slack scales with the
+                        // scene), sphere_first_t WILL report a hit: t1 <= tca if t1 is valid, else t2 = tca + half chord
+                        // <= tca + |r| / |d|, which lies beyond tca > t_min.
                         const float tca = -half_b * ia;
-                        if (tca > kTMin + slack) bound = __builtin_fminf(bound, tca + __builtin_fmaf(__builtin_fabsf(s.w), rs1, slack));
+                        if (tca > kTMin + slack && disc > 1e-6f) bound = __builtin_fminf(bound, tca + __builtin_fmaf(__builtin_fabsf(s.w), rs1, slack));
                     }
                 }
             }

@@ -88,7 +88,8 @@ struct DevScene {
     uint32_t n_cx;
     uint32_t n_bvh_nodes;  // entries of bvh_nodes
     uint32_t n_sph, n_sph_pad, n_pl, n_obj;
-    uint32_t n_box;  // scan-path entries that are boxes (0: sph_box is never read)
+    uint32_t n_box;      // scan-path entries that are boxes (0: sph_box is never read)
+    uint32_t first_box;  // the first of them (lowest object index): what a ray with an all-NaN direction hits (rt_device.h nan_ray)
     float c2max;  // >= max_j (|p_j|^2 + r_j^2), rounded up: magnitude bound used by the cull margin
     DevGrid grid;
 };

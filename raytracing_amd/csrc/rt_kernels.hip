@@ -22,6 +22,7 @@
 // exactly like the reference's scalar f32 code; the filter uses explicit fmaf and is protected by the
 // error bound derived in DESIGN.md ("Conservative filter").
 #include "rt_complex.h"
+#include "rt_grid.h"
 
 #include <cstdlib>
 
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
 
         // ---- 2. per-segment constants ----
         ScanConsts<R> c;
+        bool scan_live[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const F3 o = s[r].o, d = s[r].d;
@@ -142,15 +144,35 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             c.nod[r] = -dot(o, c.dh[r]);
             float oo = dot(o, o);
             float margin = kCullKappaU * (oo + sc.c2max);
-            c.s0[r] = s[r].live ? (oo - margin) : __builtin_inff();
+            scan_live[r] = s[r].live && !(MODE == 0 && nan_ray(d));  // all-NaN directions are settled by push_nan_rays
+            c.s0[r] = scan_live[r] ? (oo - margin) : __builtin_inff();
             c.pp[r] = f3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z);
+            if (!scan_live[r]) {  // q = -inf: fails the filter
+                c.dh[r] = f3(0.f, 0.f, 0.f);
+                c.nod[r] = 0.0f;
+                c.pp[r] = f3(0.f, 0.f, 0.f);
+            }
             c.o[r] = o; c.d[r] = d; c.a[r] = a; c.live[r] = s[r].live;
         }
         unsigned head = 0, tail = 0;
         wave_lds_sync();
+        if (MODE == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) push_nan_rays<R>(w, sc, s[r].live && !scan_live[r], r * 64u, head, tail, lane);
+        }
 
-        // ---- 3. scan the sphere list ----
-        if (STREAM)
+        // ---- 3. scan the sphere list, or walk the grid over it when every ray of the wave may ----
+        bool walk = MODE == 0 && p.grid_mode != 0;
+        if (walk) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) walk &= __ballot(scan_live[r] && !grid_admits(sc.grid, s[r].o, s[r].d)) == 0ull;
+        }
+        if (walk) {
+            unsigned long long unused = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                grid_walk<R>(sc.grid, sc.grid.cells, sc.grid.items, sc.sph_exact, s[r].o, s[r].d, c.a[r], scan_live[r], r * 64u, w, sc, head, tail, lane, unused);
+        } else if (STREAM)
             scan_tile<R, (MODE == 0 ? 0 : 2), true>(sc.sph_cull, sc.n_sph_pad, stage, c, w, sc, head, tail, lane);
         else
             scan_tile<R, (MODE == 0 ? 0 : 2), false>(tile, sc.n_sph_pad, stage, c, w, sc, head, tail, lane);
@@ -320,8 +342,14 @@ static hipError_t launch_trace_t(const TraceParams& p, int n_cu, int device, hip
     return hipGetLastError();
 }
 
-hipError_t launch_trace(const TraceParams& p, int n_cu, int device, hipStream_t stream)
+// Scenes from this many scan-path entries on walk the grid (read from global memory in this kernel); below it the LDS-resident
+// table scan is at least as fast.
+constexpr uint32_t kTraceGridMinSpheres = 256;
+
+hipError_t launch_trace(const TraceParams& p_in, int n_cu, int device, hipStream_t stream)
 {
+    TraceParams p = p_in;
+    p.grid_mode = (p.sc.grid.enabled && p.sc.n_sph >= kTraceGridMinSpheres && !getenv("RT_HIP_NO_GRID")) ? 2u : 0u;
     const bool stream_table = p.sc.n_sph_pad > (uint32_t)kTileSpheres;
     const bool cx = p.sc.n_cx > 0;
     if (p.scan_mode == 0) {

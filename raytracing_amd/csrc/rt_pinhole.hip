@@ -79,6 +79,11 @@ __device__ __forceinline__ void general_consts(ScanConsts<R>& c, int r, F3 o, F3
     const float margin = kCullKappaU * (oo + sc.c2max);
     c.s0[r] = live ? (oo - margin) : __builtin_inff();
     c.pp[r] = f3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z);
+    if (!live) {  // q = 0 * 0 - inf = -inf fails the filter, whatever the slot holds (NaNs pass it otherwise)
+        c.dh[r] = f3(0.f, 0.f, 0.f);
+        c.nod[r] = 0.0f;
+        c.pp[r] = f3(0.f, 0.f, 0.f);
+    }
 }
 
 // The table scan with the general filter.  from_global: the block's LDS holds the grid's tables instead of {p, K}, so this
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
         F3 ro[R], rd[R];
         float rior[R];
         uint32_t rm[R], rsample[R], rb[R];
-        bool live[R];
+        bool live[R], scan_live[R];
         unsigned head = 0, tail = 0;
 
         if (!do_sec) {
@@ -295,25 +300,28 @@ __global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TracePara
                 w.stash[3][slot] = d.x; w.stash[4][slot] = d.y; w.stash[5][slot] = d.z;
                 w.stash[6][slot] = a;
                 w.best[slot] = kNoHit;
-                general_consts<R>(c, r, o, d, a, live[r], sc);
+                scan_live[r] = live[r] && !nan_ray(d);  // all-NaN directions are settled by push_nan_rays
+                general_consts<R>(c, r, o, d, a, scan_live[r], sc);
             }
             wave_lds_sync();
+#pragma unroll
+            for (int r = 0; r < R; ++r) push_nan_rays<R>(w, sc, live[r] && !scan_live[r], r * 64u, head, tail, lane);
             if (true) { RT_T1(3) }
             RT_T0(5)  // region 5: grid walk / table scan of the continuing rays
             // the grid serves every ray that starts within its error budget; a wave with one that does not scans the table
             bool walk = gm != 0;
             if (walk) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) walk &= __ballot(live[r] && !grid_admits(grid, ro[r], rd[r])) == 0ull;
+                for (int r = 0; r < R; ++r) walk &= __ballot(scan_live[r] && !grid_admits(grid, ro[r], rd[r])) == 0ull;
             }
             if (walk) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const float a = dot(rd[r], rd[r]);
                     if constexpr (STREAM)  // grid mode 2
-                        grid_walk<R>(grid, grid.cells, grid.items, sc.sph_exact, ro[r], rd[r], a, live[r], r * 64u, w, sc, head, tail, lane, my_dbg);
+                        grid_walk<R>(grid, grid.cells, grid.items, sc.sph_exact, ro[r], rd[r], a, scan_live[r], r * 64u, w, sc, head, tail, lane, my_dbg);
                     else  // grid mode 1
-                        grid_walk<R>(grid, (LdsU32*)grid_lds, (LdsU16*)(grid_lds + grid.n_cells), (LdsGV4*)tiles, ro[r], rd[r], a, live[r], r * 64u, w, sc,
+                        grid_walk<R>(grid, (LdsU32*)grid_lds, (LdsU16*)(grid_lds + grid.n_cells), (LdsGV4*)tiles, ro[r], rd[r], a, scan_live[r], r * 64u, w, sc,
                                      head, tail, lane, my_dbg);
                 }
             } else {
