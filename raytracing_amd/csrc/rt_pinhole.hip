@@ -29,7 +29,14 @@ namespace {
 #endif
 
 
-constexpr int kPinThreads = 512;  // 8 waves share the two LDS tables; 2 blocks per CU = 4 waves per SIMD
+// 512 threads: 8 waves share the LDS tables, 2 blocks per CU = 4 waves per SIMD at 128 VGPRs (with spills).  Measured alternatives
+// (DESIGN.md §4.5): 384 threads / 3 waves per SIMD / 168 VGPRs and 256 threads / 2 waves per SIMD / 187 VGPRs without spills are
+// both slower (C2 frame 9.9 ms and 7.7 ms against 6.0 ms): the grid walk lives on occupancy, not on registers.
+#ifndef RT_PIN_THREADS
+#define RT_PIN_THREADS 512
+#define RT_PIN_WAVES 4
+#endif
+constexpr int kPinThreads = RT_PIN_THREADS;
 
 // One entry of the shared-origin table.  Every primary ray of a Projector points from O to
 // T(i, j) = corner + i us + j vs, so with q = p - O the projection numerator q . (T - O) = A + i B + j C is affine in the
@@ -99,7 +106,7 @@ __device__ __forceinline__ void general_scan(bool from_global, const float4* til
 
 // STREAM = false: the sphere tables (<= kTileSpheres spheres) live in LDS.  STREAM = true: both are streamed from global / L2.
 template <int R, bool STREAM, bool CX>
-__global__ __launch_bounds__(kPinThreads, 4) void pinhole_kernel(const TraceParams p)
+__global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(const TraceParams p)
 {
     extern __shared__ float4 tiles[];  // [n_sph_pad] general {p, K}, then 3 floats per sphere {A, B, C} / sK (LDS mode), then the BVH top
     __shared__ WaveLds<R> wl[kPinThreads / 64];

@@ -834,6 +834,28 @@ def test_bench_sharded_path_and_stored_checksums(engine):
         assert sharding.frame_checksum(img) == int(stored[key], 16) and segs == one.segments()
 
 
+@pytest.mark.parametrize("case,seed0", [(497, 200), (441, 200), (6, 0), (36, 0), (91, 0), (16, 0), (2, 0)])
+def test_grid_and_cull_list_cases_against_the_oracle(engine, case, seed0):
+    """Configurations of tools/fuzz_pinhole.py that once broke the Projector kernel's cull list / grid walk, replayed against the
+    oracle: a sphere grazed within the reference's absolute 1e-6 discriminant threshold in a scene 0.2 units across (the walk's
+    early stop took it for a hit: cases 497, 441 of seed 200), boxes entered from inside (NaN rays, cases 6, 36, 91), a crowd of
+    spheres around the projector origin (more than a cull list holds, case 16), a mirror plane behind the cloud (continuing rays
+    that start outside the grid's origin range, case 2)."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import fuzz_pinhole as fz
+
+    fz.seed0 = seed0
+    gen, objs, st, scale, n_sph, cu, cv = fz.make_case(case)
+    got = engine.Scene(objs).render(gen, 2, st, seed=case)
+    want = ob.OracleScene(objs).render(gen, 2, st.infinity_distance, st.max_bounces, seed=case, threads=8)
+    for a, b in zip(got[:4], want[:4]):
+        assert same(a, b)
+    assert got[4] == want[4]
+
+
 @pytest.mark.parametrize("n_extra", [20, 400, 1200])
 def test_nan_rays_from_box_interiors_hit_boxes_as_in_the_reference(engine, n_extra):
     """A ray that starts inside a rotation-0 box "enters" it at t_min with a zero normal (axis_aligned_box.rs:33-41, 70-95), so its
