@@ -210,11 +210,13 @@ int rt_hip_render_dev_noalloc(const rt_scene* scene, const RtRayGenerator* gen, 
                               int32_t* d_first_id, float* d_first_t, uint32_t* d_seg_count, uint64_t* d_total_segments,
                               void* stream);
 
-/* Number of objects / spheres / planes held by a scene (for harnesses and roofline accounting). */
+/* Number of objects / scan-path entries (rotation-0 spheres and boxes) / planes held by a scene (for harnesses and roofline
+ * accounting). */
 int rt_hip_scene_counts(const rt_scene* scene, uint64_t* n_objects, uint64_t* n_spheres, uint64_t* n_planes);
 
-/* Tuning / diagnostics: 0 = conservative FMA cull + exact confirm (default), 1 = exact discriminant as
- * the filter (op-for-op, no cull). Results are bit-identical; only speed differs. */
+/* Tuning / diagnostics: 0 = conservative filters + exact confirm (default; the list scan is pruned by per-wave cull lists and a
+ * uniform grid over the spheres where the scene is large enough), 1 = the reference's own discriminant as the filter over the
+ * whole list (op-for-op, no cull, general kernel). Results are bit-identical; only speed differs. */
 int rt_hip_set_scan_mode(int mode);
 
 #ifdef __cplusplus
