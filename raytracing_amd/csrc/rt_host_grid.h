@@ -11,7 +11,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
-#include <cstdlib>
 #include <limits>
 #include <vector>
 
@@ -55,8 +54,7 @@ inline GridHost build_grid(const std::vector<float4>& sph_exact, const std::vect
     double cmax = 0.0;
     for (int a = 0; a < 3; ++a) cmax = std::max(cmax, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
     const double D = 3.0 * radius0 * 1.01;
-    double E = 3e-3 * D;
-    if (const char* e = getenv("RT_HIP_GRID_E_MULT")) E *= atof(e);  // EXPLORATION ONLY (unsafe below 1)
+    const double E = 3e-3 * D;
     if (!(E > 64.0 * 0x1p-24 * (cmax + 3.0 * radius0))) return out;  // scene far from the coordinate origin relative to its size
     for (int a = 0; a < 3; ++a) {
         lo[a] -= 2.0 * E;
@@ -67,8 +65,7 @@ inline GridHost build_grid(const std::vector<float4>& sph_exact, const std::vect
         ext[a] = hi[a] - lo[a];
         vol *= ext[a];
     }
-    double cs = std::cbrt(vol / (double)n);
-    if (const char* e = getenv("RT_HIP_GRID_CELL_MULT")) cs *= atof(e);  // exploration
+    double cs = std::cbrt(vol / (double)n);  // measured on C2: 1.25x / 1.5x larger cells cost 7 % / 12 % of the frame
     // every cell at least as wide as the typical inflated sphere box would make a sphere span 8+ cells: keep cells >= 2 E
     cs = std::max(cs, 2.0 * E);
     uint32_t dim[3];

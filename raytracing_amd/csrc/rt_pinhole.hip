@@ -308,7 +308,6 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
                 w.stash[6][slot] = a;
                 w.best[slot] = kNoHit;
                 scan_live[r] = live[r] && !nan_ray(d);  // all-NaN directions are settled by push_nan_rays
-                general_consts<R>(c, r, o, d, a, scan_live[r], sc);
             }
             wave_lds_sync();
 #pragma unroll
@@ -332,6 +331,8 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
                                      head, tail, lane, my_dbg);
                 }
             } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) general_consts<R>(c, r, ro[r], rd[r], dot(rd[r], rd[r]), scan_live[r], sc);
                 general_scan<R, STREAM>(gm == 1, tileG, n_pad, stage, c, w, sc, head, tail, lane);
             }
         }
