@@ -458,7 +458,10 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
     }
 }
 
-constexpr int kR = 2;
+#ifndef RT_PIN_R
+#define RT_PIN_R 1
+#endif
+constexpr int kR = RT_PIN_R;
 
 inline bool stream_mode(const TraceParams& p) { return p.sc.n_sph_pad > (uint32_t)kTileSpheres; }
 constexpr size_t kLdsPerBlock = 80 * 1024;  // two 512-thread blocks per CU share 160 KB
