@@ -41,7 +41,7 @@ struct Context {
     bool last_valid = false;
 };
 Context g_ctx;
-constexpr unsigned kCounterRing = 1024;
+constexpr unsigned kCounterRing = 64;  // per-launch sets of work counters (kUnitCounterBytes each), used round-robin
 
 int fail(int code, const std::string& msg)
 {
@@ -222,7 +222,7 @@ Workspace context_workspace()
 {
     Workspace w{};
     w.fixed = false;
-    w.next_unit = g_ctx.counters + (g_ctx.next_counter++ % kCounterRing);
+    w.next_unit = g_ctx.counters + (size_t)(g_ctx.next_counter++ % kCounterRing) * (rt::kUnitCounterBytes / sizeof(unsigned long long));
     w.fb_q = g_ctx.fb_q;
     w.fb_q_bytes = g_ctx.fb_q_bytes;
     w.secq = g_ctx.secq;
@@ -270,7 +270,7 @@ int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream,
 {
     p.next_unit = ws.next_unit;
     p.total_segments = d_total;
-    HIP_TRY(hipMemsetAsync(p.next_unit, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(p.next_unit, 0, rt::kUnitCounterBytes, stream));
     if (d_total) HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), stream));
     bool pinhole = use_pinhole(p);
     if (pinhole) {
@@ -363,7 +363,7 @@ int rt_hip_init(int device_ordinal)
         HIP_TRY(hipSetDevice(device_ordinal));
     }
     if (!g_ctx.ready) {
-        HIP_TRY(hipMalloc((void**)&g_ctx.counters, kCounterRing * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void**)&g_ctx.counters, kCounterRing * rt::kUnitCounterBytes));
         HIP_TRY(hipEventCreateWithFlags(&g_ctx.last_done, hipEventDisableTiming));
         // this device's copy of the no-alloc workspace (rt_scratch.hip); device_ordinal is current
         void* scratch = nullptr;

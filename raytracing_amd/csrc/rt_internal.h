@@ -122,7 +122,7 @@ struct TraceParams {
     uint32_t* n_points;
     RtBounceRecord* records;
     unsigned long long* total_segments;  // accumulated with atomics; zeroed by the launcher
-    unsigned long long* next_unit;       // work counter; zeroed by the launcher
+    unsigned long long* next_unit;       // work counters (kUnitCounterBytes, zeroed by the launcher); the general kernel uses the first
     int scan_mode;                       // 0 = conservative cull, 1 = exact discriminant filter
     // pinhole kernel only
     uint32_t* secq;     // per-wave rings of continuing rays: [grid waves][kSecFields][kSecCap] dwords
@@ -133,18 +133,23 @@ struct TraceParams {
     uint32_t grid_mode;      // pinhole kernel: 0 no grid, 1 grid in LDS, 2 grid in global memory (pinhole_grid_mode, set before sizing)
 };
 
+// Work counters of the Projector kernel: batch b of 64 units belongs to counter b % kUnitCounters; one 128-byte line each.
+constexpr unsigned kUnitCounters = 32;
+constexpr unsigned kUnitCounterStride = 16;  // in 64-bit words
+constexpr size_t kUnitCounterBytes = (size_t)kUnitCounters * kUnitCounterStride * sizeof(unsigned long long);  // 4,096
+
 constexpr unsigned kSecCap = 256;    // entries per wave ring (a primary step adds <= 128 to a residue < 128)
 constexpr unsigned kSecFields = 10;  // o.xyz d.xyz ior cell sample bounce
 
 // ---- fixed workspace of rt_hip_render_dev_noalloc (rt_scratch.hip): one static device array, carved into regions ----
 constexpr size_t kNoAllocMaxCells = 1u << 19;       // cells per call: 32 B of accumulators each
 constexpr size_t kNoAllocMaxSpheres = 1u << 14;     // scan-path spheres (streamed shared-origin table, 16 B each)
-constexpr size_t kNoAllocHeaderBytes = 4096;        // work counter (8 B used)
+constexpr size_t kNoAllocHeaderBytes = 4096;        // work counters (kUnitCounterBytes)
 constexpr size_t kNoAllocTableBytes = kNoAllocMaxSpheres * sizeof(float4);
 constexpr size_t kNoAllocRingBytes = (size_t)512 * 8 * kSecFields * kSecCap * sizeof(uint32_t);  // 512 resident blocks x 8 waves (256 CUs x 2)
 constexpr size_t kNoAllocFbBytes = kNoAllocMaxCells * 4 * sizeof(unsigned long long);
 constexpr size_t kNoAllocScratchBytes = kNoAllocHeaderBytes + kNoAllocTableBytes + kNoAllocRingBytes + kNoAllocFbBytes;  // 58,986,496 B (56.3 MiB)
-static_assert(kNoAllocHeaderBytes % 256 == 0 && kNoAllocTableBytes % 256 == 0 && kNoAllocRingBytes % 256 == 0, "regions stay 256-byte aligned");
+static_assert(kNoAllocHeaderBytes >= kUnitCounterBytes && kNoAllocHeaderBytes % 256 == 0 && kNoAllocTableBytes % 256 == 0 && kNoAllocRingBytes % 256 == 0, "regions stay 256-byte aligned");
 // Device address of the calling thread's current device's copy of the array (hipGetSymbolAddress; no allocation).
 hipError_t noalloc_scratch_address(void** out);
 

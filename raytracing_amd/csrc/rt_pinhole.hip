@@ -112,6 +112,9 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
     __shared__ WaveLds<R> wl[kPinThreads / 64];
     __shared__ float4 stage_all[STREAM ? (kPinThreads / 64) * 128 : 1];
     __shared__ float4 cull_all[kPinThreads / 64][R][kCullCap];  // per wave and slot group: the spheres its current cells can reach
+    // Per work unit: the primary ray's direction, its cell indices and the filter threshold.  Every sample of a unit starts with the
+    // same ray (the reference's Projector has no jitter), so these are worked out when the unit is dealt and read back each step.
+    __shared__ float unit_ray_all[kPinThreads / 64][R][6][64];
 
     const unsigned lane = lane_id();
     const unsigned wave = threadIdx.x >> 6;
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
     }
     unsigned long long my_segments = 0, my_dbg = 0;
     bool exhausted = false, prim_done = false;
+    unsigned long long chunk_next = 0, chunk_end = 0;  // the wave's current batch of work units (wave-uniform)
     // cull lists (wave-uniform state): entries in the list, and whether the group's cells changed since it was built
     unsigned n_cull[R];
     bool cull_stale[R];
@@ -172,6 +176,8 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
         cull_stale[r] = true;
     }
     const unsigned long long total_units = (unsigned long long)p.cell_count * p.units_per_cell;
+    const unsigned long long total_batches = (total_units + 63ull) / 64ull;
+    unsigned ctr = gwave % kUnitCounters, ctr_done = 0;  // the work counter this wave draws from; counters it has seen run out
     const uint32_t max_b = p.st.max_bounces;
 
     for (;;) {
@@ -199,16 +205,38 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
                 bool need_unit = (um[r] == 0xffffffffu);
                 unsigned long long need = __ballot(need_unit);
                 if (need && !exhausted) {
-                    unsigned cnt = (unsigned)__builtin_popcountll(need);
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(p.next_unit, (unsigned long long)cnt);
-                    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
-                           __builtin_amdgcn_readfirstlane((unsigned)base);
-                    if (base + cnt >= total_units) exhausted = true;
+                    // Units come in batches of 64 from kUnitCounters interleaved work counters (batch b belongs to counter
+                    // b % kUnitCounters): all waves of the chip adding to ONE address took, by that counter alone, the time of a
+                    // third of a C2 frame.  A wave starts at its own counter and moves on when one runs out, so neighbouring
+                    // batches are still in flight at the same time (cull lists, grid cells and accumulators stay cache-warm).
+                    // Lanes a depleted batch cannot serve (ragged units) sit this step out and are served from the next.
+                    if (chunk_next == chunk_end) {
+                        for (;;) {
+                            unsigned long long v = 0;
+                            if (lane == 0) v = atomicAdd(p.next_unit + (size_t)ctr * kUnitCounterStride, 1ull);
+                            v = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)v);
+                            const unsigned long long batch = v * kUnitCounters + ctr;
+                            if (batch < total_batches) {
+                                chunk_next = batch * 64ull;
+                                chunk_end = chunk_next + 64ull < total_units ? chunk_next + 64ull : total_units;
+                                break;
+                            }
+                            ctr = (ctr + 1u) % kUnitCounters;
+                            if (++ctr_done == kUnitCounters) {
+                                exhausted = true;
+                                break;
+                            }
+                        }
+                    }
+                    const unsigned long long avail = chunk_end - chunk_next;
+                    const unsigned cnt = (unsigned)__builtin_popcountll(need);
+                    const unsigned take = avail < cnt ? (unsigned)avail : cnt;
+                    const unsigned long long base = chunk_next;
+                    chunk_next += take;
                     cull_stale[r] = true;
-                    if (need_unit) {
+                    if (need_unit && mbcnt64(need) < take) {
                         unsigned long long unit = base + mbcnt64(need);
-                        if (unit < total_units) {
+                        {
                             uint32_t m = (uint32_t)(unit / p.units_per_cell);
                             uint32_t k = (uint32_t)(unit - (unsigned long long)m * p.units_per_cell);
                             um[r] = m;
@@ -217,6 +245,18 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
                             uend[r] = e < p.spp ? e : p.spp;
                             usegs[r] = 0;
                             ax[r] = ay[r] = az[r] = 0;
+                            F3 o_unused = O, dir;
+                            float ior_unused = 0.f;
+                            primary_ray(p, m, o_unused, dir, ior_unused);
+                            uint32_t ci, cj;
+                            cell_indices(p, m, ci, cj);
+                            const F3 corner = f3(p.gen.corner[0], p.gen.corner[1], p.gen.corner[2]);
+                            const F3 us = f3(p.gen.u_step[0], p.gen.u_step[1], p.gen.u_step[2]), vs = f3(p.gen.v_step[0], p.gen.v_step[1], p.gen.v_step[2]);
+                            const F3 dv = ((corner + ((float)ci * us)) + ((float)cj * vs)) - O;  // the reference's target - origin (scene_config.rs:98-100)
+                            float (*ur)[64] = unit_ray_all[wave][r];
+                            ur[0][lane] = dir.x; ur[1][lane] = dir.y; ur[2][lane] = dir.z;
+                            ur[3][lane] = (float)ci; ur[4][lane] = (float)cj;
+                            ur[5][lane] = __builtin_sqrtf(dot(dv, dv)) * (1.0f - 0x1p-20f);  // a lower bound of |target - O|
                         }
                     }
                 }
@@ -235,9 +275,9 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
                 rsample[r] = usample[r];
                 rb[r] = 0;
                 ro[r] = O;
-                rd[r] = f3(0.f, 0.f, 0.f);
+                const float (*ur)[64] = unit_ray_all[wave][r];  // written by this lane when its unit was dealt
+                rd[r] = live[r] ? f3(ur[0][lane], ur[1][lane], ur[2][lane]) : f3(0.f, 0.f, 0.f);
                 rior[r] = p.gen.current_ior;
-                if (live[r]) primary_ray(p, um[r], ro[r], rd[r], rior[r]);
                 const float a = dot(rd[r], rd[r]);
                 const unsigned slot = r * 64 + lane;
                 w.stash[0][slot] = ro[r].x; w.stash[1][slot] = ro[r].y; w.stash[2][slot] = ro[r].z;
@@ -245,15 +285,9 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
                 w.stash[6][slot] = a;
                 w.best[slot] = kNoHit;
                 // shared-origin filter constants: cell indices (exact in f32) and a lower bound of |target - O|
-                // (recomputed every step: parking them per unit in registers or private memory measured slower)
-                uint32_t ci, cj;
-                cell_indices(p, live[r] ? um[r] : 0u, ci, cj);
-                c.ci[r] = (float)ci;
-                c.cj[r] = (float)cj;
-                const F3 corner = f3(p.gen.corner[0], p.gen.corner[1], p.gen.corner[2]);
-                const F3 us = f3(p.gen.u_step[0], p.gen.u_step[1], p.gen.u_step[2]), vs = f3(p.gen.v_step[0], p.gen.v_step[1], p.gen.v_step[2]);
-                const F3 dv = ((corner + (c.ci[r] * us)) + (c.cj[r] * vs)) - O;  // the reference's target - origin (scene_config.rs:98-100)
-                c.lt[r] = live[r] ? __builtin_sqrtf(dot(dv, dv)) * (1.0f - 0x1p-20f) : __builtin_inff();  // dead slots are masked by `live`
+                c.ci[r] = live[r] ? ur[3][lane] : 0.0f;
+                c.cj[r] = live[r] ? ur[4][lane] : 0.0f;
+                c.lt[r] = live[r] ? ur[5][lane] : __builtin_inff();  // dead slots are masked by `live`
             }
             wave_lds_sync();
             if (true) { RT_T1(2) }
@@ -486,7 +520,7 @@ template <bool STREAM>
 uint32_t bvh_lds_fit(const TraceParams& p)
 {
     hipFuncAttributes fa{};
-    if (hipFuncGetAttributes(&fa, (const void*)pinhole_kernel<2, STREAM, true>) != hipSuccess) return 0;
+    if (hipFuncGetAttributes(&fa, (const void*)pinhole_kernel<kR, STREAM, true>) != hipSuccess) return 0;
     const size_t used = fa.sharedSizeBytes + table_lds(p) + 512;
     const size_t room = used < kLdsPerBlock ? (kLdsPerBlock - used) / sizeof(BvhNode) : 0;
     uint32_t n = p.sc.n_bvh_nodes < kBvhLdsNodes ? p.sc.n_bvh_nodes : kBvhLdsNodes;
