@@ -71,6 +71,9 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
     unsigned long long my_segments = 0;
     bool exhausted = false;  // work counter ran past the last unit (wave-uniform)
     const unsigned long long total_units = (unsigned long long)p.cell_count * p.units_per_cell;
+    const unsigned long long total_batches = (total_units + 63ull) / 64ull;
+    unsigned long long chunk_next = 0, chunk_end = 0;  // the wave's current batch of work units (wave-uniform)
+    unsigned ctr = (blockIdx.x * (kBlockThreads / 64) + wave) % kUnitCounters, ctr_done = 0;
     bool wave_done = false;
     const uint32_t max_b = p.st.max_bounces;
     const uint64_t stride_pts = (uint64_t)max_b + 1;
@@ -84,15 +87,34 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
                 bool need_unit = !s[r].live && (s[r].m == 0xffffffffu);
                 unsigned long long need = __ballot(need_unit);
                 if (need && !exhausted) {
-                    unsigned cnt = (unsigned)__builtin_popcountll(need);
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(p.next_unit, (unsigned long long)cnt);
-                    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
-                           __builtin_amdgcn_readfirstlane((unsigned)base);
-                    if (base + cnt >= total_units) exhausted = true;
-                    if (need_unit) {
+                    // batches of 64 units from kUnitCounters interleaved work counters (see rt_pinhole.hip: one counter for the
+                    // whole chip serialises large launches); lanes a depleted batch cannot serve are served from the next one
+                    if (chunk_next == chunk_end) {
+                        for (;;) {
+                            unsigned long long v = 0;
+                            if (lane == 0) v = atomicAdd(p.next_unit + (size_t)ctr * kUnitCounterStride, 1ull);
+                            v = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)v);
+                            const unsigned long long batch = v * kUnitCounters + ctr;
+                            if (batch < total_batches) {
+                                chunk_next = batch * 64ull;
+                                chunk_end = chunk_next + 64ull < total_units ? chunk_next + 64ull : total_units;
+                                break;
+                            }
+                            ctr = (ctr + 1u) % kUnitCounters;
+                            if (++ctr_done == kUnitCounters) {
+                                exhausted = true;
+                                break;
+                            }
+                        }
+                    }
+                    const unsigned long long avail = chunk_end - chunk_next;
+                    const unsigned cnt = (unsigned)__builtin_popcountll(need);
+                    const unsigned take = avail < cnt ? (unsigned)avail : cnt;
+                    const unsigned long long base = chunk_next;
+                    chunk_next += take;
+                    if (need_unit && mbcnt64(need) < take) {
                         unsigned long long unit = base + mbcnt64(need);
-                        if (unit < total_units) {
+                        {
                             uint32_t m, k;
                             if (p.units_per_cell == 1) {
                                 m = (uint32_t)unit;
