@@ -200,7 +200,7 @@ def main():
         achieved = None if insts is None else insts * share / (render_ms * 1e-3) / 1e9
         roof = {
             "bound": "valu_issue",
-            "kernel": "pinhole_kernel<2, %s, false> (Projector render loop)" % ("false" if n_sph <= 1024 else "true"),
+            "kernel": "pinhole_kernel<1, %s, false> (Projector render loop, one ray per lane)" % ("false" if n_sph <= 1024 else "true"),
             "achieved": achieved,
             "peak": PEAK_VALU_GINST,
             "unit": "Ginst/s",

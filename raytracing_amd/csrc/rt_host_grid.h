@@ -1,11 +1,16 @@
 // rt_host_grid.h — host-side build of the uniform grid the Projector kernel's continuing rays walk.
 //
 // Every scan-path entry j (a sphere, or the bounding sphere of a rotation-0 box) is registered in each cell that its box
-// [p - (r + E), p + (r + E)] touches.  E covers everything the float arithmetic of the device can get wrong about WHERE a hit
-// is: the reference's discriminant test (sphere.rs:13-18) accepts rays that pass up to sqrt(25 u) |o - p| outside the sphere
-// (u = 2^-24; 25 u |o - p|^2 |d|^2 bounds the rounding of its discriminant), the t it returns is off by at most as much again,
-// and the cell walk itself places points with an error of a few u times the coordinates.  With every admitted ray origin
-// within 2 * radius of the grid centre, |o - p| <= 3 * radius =: D, and E = 3e-3 * D >= 2 * sqrt(25 u) * D + the walk's error.
+// [p - (r + E_j), p + (r + E_j)] touches.  E_j covers everything the float arithmetic of the device can get wrong about WHERE
+// a hit is.  With X = o + t d the point the reference's t (sphere.rs:13-26, 48) stands for and D^ its float discriminant,
+//   a (|X - p|^2 - r^2) = (a t + half_b)^2 - disc = (D^ - disc) + 2 sqrt(D^) (err(half_b) + err(t) a) + ...
+// |D^ - disc| <= 25 u a L^2 (u = 2^-24, L = |o - p|: the rounding of the five products and sums behind it), sqrt(D^) <=
+// |d| r' with r' = sqrt(r^2 + 25 u L^2), the bracket <= 6 u (L + r) |d|.  Hence |X - p|^2 <= r^2 + 25 u L^2 + 12 u (L + r) r'.
+// With every admitted ray origin within 2 * radius of the grid centre, L <= 3 * radius =: D, and
+//   E_j = 1.1 * (sqrt(r^2 + 25 u D^2 + 12 u (D + r) r') - r) + 2e-4 * D,
+// the last term for the walk itself, which places points and cell boundaries with an error of a few hundred u times the
+// coordinates.  (Until the end of round 2 one E = 3e-3 * D served every sphere: the r -> 0 limit of the above, 0.7 units on a
+// scene whose spheres have radii 0.5 .. 2; an entry sat in 3.6 cells instead of 2.5.)
 // Rays that start farther away do not use the grid (DevGrid::origin_r2).
 #pragma once
 #include <algorithm>
@@ -54,7 +59,12 @@ inline GridHost build_grid(const std::vector<float4>& sph_exact, const std::vect
     double cmax = 0.0;
     for (int a = 0; a < 3; ++a) cmax = std::max(cmax, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
     const double D = 3.0 * radius0 * 1.01;
-    const double E = 3e-3 * D;
+    const double u25 = 25.0 * 0x1p-24, u12 = 12.0 * 0x1p-24;
+    auto margin = [&](double r) {
+        const double r1 = std::sqrt(r * r + u25 * D * D);
+        return 1.1 * (std::sqrt(r * r + u25 * D * D + u12 * (D + r) * r1) - r) + 2e-4 * D;
+    };
+    const double E = margin(0.0);  // the largest margin any entry can have: bounds and the cell size floor use it
     if (!(E > 64.0 * 0x1p-24 * (cmax + 3.0 * radius0))) return out;  // scene far from the coordinate origin relative to its size
     for (int a = 0; a < 3; ++a) {
         lo[a] -= 2.0 * E;
@@ -86,7 +96,7 @@ inline GridHost build_grid(const std::vector<float4>& sph_exact, const std::vect
     // not needed because E already contains the device's placement error
     auto range = [&](uint32_t j, int a, uint32_t& c0, uint32_t& c1) {
         const double p = a == 0 ? sph_exact[j].x : a == 1 ? sph_exact[j].y : sph_exact[j].z;
-        const double r = std::fabs((double)sph_exact[j].w) + E;
+        const double r0 = std::fabs((double)sph_exact[j].w), r = r0 + margin(r0);
         const double f0 = std::floor((p - r - lo[a]) / (double)csf), f1 = std::floor((p + r - lo[a]) / (double)csf);
         c0 = (uint32_t)std::min(std::max(f0, 0.0), (double)dim[a] - 1.0);
         c1 = (uint32_t)std::min(std::max(f1, 0.0), (double)dim[a] - 1.0);
