@@ -288,6 +288,7 @@ int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream,
         }
         p.prim_margin = (float)(c2 * 64.0 * 0x1p-24 * (1.0 + 1e-6));
         p.grid_mode = rt::pinhole_grid_mode(p);  // decides the LDS layout, hence the resident blocks the rings are sized for
+        p.tile_shift = ws.fixed ? 0 : rt::pinhole_tile_shift(p);  // the fixed workspace has no room for tile lists: its calls cull the whole table
         if (int rc = ensure_scratch(ws, ws.secq, ws.secq_bytes, g_ctx.secq, g_ctx.secq_bytes, rt::pinhole_secq_bytes(p, g_ctx.n_cu),
                                     "the continuing-ray rings"))
             return rc;

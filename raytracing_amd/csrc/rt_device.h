@@ -389,16 +389,25 @@ __device__ __forceinline__ void scan_tile(const float4* tile, unsigned count, fl
 // ---------------------------------------------------------------------------------------------------
 // Wave-level cull of the shared-origin table.  The work units of one slot group are dealt to neighbouring
 // lanes, so the 64 rays of a group cover a short run of generator cells, and they keep those cells for unit_samples steps.
-// A sphere whose affine form cannot reach the smallest threshold of the group anywhere in the group's bounding box of cell
-// indices cannot pass for any of its rays, in any of those steps; the few that can are copied to a per-group LDS list once,
-// and the primary scan of the following steps reads that list instead of the whole table.  The per-ray test on the list is
-// the expression h = fma(i, B', fma(j, C', A')), so every ray sees exactly the candidates it would have seen in the full scan.
+// A sphere that no ray of the group's bounding box of cell indices can pass is of no interest in any of those steps; the few
+// that remain are copied to a per-group LDS list once, and the primary scan of the following steps reads that list instead
+// of the whole table.  The per-ray test on the list is the expression h = fma(i, B', fma(j, C', A')) against the ray's own
+// threshold, so every ray sees exactly the candidates it would have seen in the full scan.
 //
-// Bound.  h(i, j) = fl(fl(a + j c) + i b) is the value the per-ray test computes.  With T = |a| + jmax |c| + imax |b| and
-// u = 2^-24, |h(i, j) - (a + j c + i b)| <= 2.01 u T for every cell of the box, and the same holds for the centre value hc,
-// so |h(i, j)| <= |hc| + dj |c| + di |b| + 4.02 u T with (di, dj) the half extents.  The code evaluates that bound with FMAs
-// (three more roundings, each below u T), adds 8 u T instead of 4.02 u T and scales by 1 + 2^-20: a sphere is dropped only
-// if even the inflated bound stays below the smallest threshold.  inf entries ("always") and NaNs survive.
+// Bound.  A ray passes when |h(i, j)| >= lt(i, j), h affine in the cell indices and lt = |v(i, j)| (1 - 2^-20), v = target - O
+// affine too.  Both sides move across the box, nearly in step for a sphere close to the line of sight, so bounding them
+// separately (max |h| against min lt: rounds 1 and 2 until here) keeps every sphere within ~10 sphere radii of an off-axis
+// group.  Instead the cull bounds the difference: |v| is convex, so with x_c the box centre, L_c = |v(x_c)| and
+// g = grad |v|(x_c) = (v_c . us, v_c . vs) / L_c,
+//     |v(x)| >= L_c + g . (x - x_c)                      for every x,
+//     +-h(x) - |v(x)| <= (+-h_c - L_c) + di |+-b - g_u| + dj |+-c - g_v|   over the box (half extents di, dj).
+// If that is negative for both signs (by more than the rounding below) no ray of the group passes.  Rounding, u = 2^-24:
+// the per-ray h and the centre value h_c are each within 2.01 u T of the real affine form, T = |a| + jmax |c| + imax |b|;
+// the per-ray v is computed with five roundings per component (scene_config.rs:98-100), each below u m_k with m_k =
+// |corner_k| + imax |us_k| + jmax |vs_k| + |O_k|, so lt(i, j) >= |v|(1 - 2^-19) - 5 u M with M = |m|; v_c, L_c, g are computed
+// here with errors of the same size, which reach the bound through L_c (<= 8 u M) and through g times the half extents
+// (W = di |us| + dj |vs| times 8 u (1 + M / L_c)); the dozen operations of the bound itself each round below u (T + M).
+// Allowed: 12 u T + 32 u M + 2^-19 (L_c + W) + 8 u W (1 + M / L_c).  inf entries ("always") and NaNs survive every compare.
 // ---------------------------------------------------------------------------------------------------
 constexpr unsigned kCullCap = 40;  // list entries per slot group; a group that needs more falls back to the full table scan
 
@@ -415,46 +424,178 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// The Projector as the cull needs it (wave-uniform): v(i, j) = (corner - O) + i us + j vs, and M (see above; it grows with the
+// largest cell indices of the launch).
+struct CullGeom {
+    F3 c0, us, vs;
+    float M;
+};
+__device__ __forceinline__ CullGeom cull_geom(const DevGen& g)
+{
+    CullGeom q;
+    q.c0 = f3(g.corner[0] - g.a[0], g.corner[1] - g.a[1], g.corner[2] - g.a[2]);
+    q.us = f3(g.u_step[0], g.u_step[1], g.u_step[2]);
+    q.vs = f3(g.v_step[0], g.v_step[1], g.v_step[2]);
+    const float iu = (float)g.count_u, jv = (float)g.count_v;
+    float m[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        m[k] = (__builtin_fabsf(g.corner[k]) + __builtin_fabsf(g.a[k])) + (iu * __builtin_fabsf(g.u_step[k]) + jv * __builtin_fabsf(g.v_step[k]));
+    q.M = __builtin_sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) * 1.001f;
+    return q;
+}
+// The same from the kernel's argument block (TraceParams is the kernel's only argument, so the block starts with it), read
+// where it is needed: a cull happens once per eight steps, and thirteen more scalar registers held across the whole loop
+// push the grid's constants out of theirs (reloaded a hundred times per walk: 8 % of a C2 frame, measured).
+__device__ __forceinline__ CullGeom cull_geom_from_kernarg(size_t gen_offset)
+{
+    const char __attribute__((address_space(4)))* kp = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));  // not loop-invariant as far as the optimiser can tell
+    const DevGen __attribute__((address_space(4)))* gp = reinterpret_cast<const DevGen __attribute__((address_space(4)))*>(kp + gen_offset);
+    DevGen g;
+    g.count_u = gp->count_u;
+    g.count_v = gp->count_v;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g.a[k] = gp->a[k];
+        g.corner[k] = gp->corner[k];
+        g.u_step[k] = gp->u_step[k];
+        g.v_step[k] = gp->v_step[k];
+    }
+    return cull_geom(g);
+}
+
+__device__ __forceinline__ float sgpr(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+
+// The bound for one box of cell indices (all members wave-uniform, held in scalar registers).
+struct CullBox {
+    float ic, jc, di, dj, imax, jmax, Lc, gu, gv, slop0;
+};
+__device__ __forceinline__ CullBox cull_box(const CullGeom& q, float imin, float imax, float jmin, float jmax)
+{
+    CullBox b;
+    const float u = 0x1p-24f;
+    b.imax = sgpr(imax);
+    b.jmax = sgpr(jmax);
+    // cell indices are integers below 2^24: sums, differences and halves are exact
+    b.ic = sgpr(0.5f * (imin + imax));
+    b.di = sgpr(0.5f * (imax - imin));
+    b.jc = sgpr(0.5f * (jmin + jmax));
+    b.dj = sgpr(0.5f * (jmax - jmin));
+    const F3 vc = f3(__builtin_fmaf(b.ic, q.us.x, __builtin_fmaf(b.jc, q.vs.x, q.c0.x)), __builtin_fmaf(b.ic, q.us.y, __builtin_fmaf(b.jc, q.vs.y, q.c0.y)),
+                     __builtin_fmaf(b.ic, q.us.z, __builtin_fmaf(b.jc, q.vs.z, q.c0.z)));
+    b.Lc = sgpr(__builtin_sqrtf(dot(vc, vc)));
+    b.gu = sgpr(dot(vc, q.us) / b.Lc);  // L_c = 0: NaN, and every sphere is kept
+    b.gv = sgpr(dot(vc, q.vs) / b.Lc);
+    const float W = b.di * __builtin_sqrtf(dot(q.us, q.us)) + b.dj * __builtin_sqrtf(dot(q.vs, q.vs));
+    b.slop0 = sgpr(32.0f * u * q.M + 0x1p-19f * (b.Lc + W) + 8.0f * u * W * (1.0f + q.M / b.Lc));
+    return b;
+}
+// May a ray of the box pass entry {a, b, c}?  ("not provably none": NaNs and inf entries pass)
+__device__ __forceinline__ bool cull_pass(const CullBox& x, float a, float b, float c)
+{
+    const float hc = __builtin_fmaf(x.ic, b, __builtin_fmaf(x.jc, c, a));
+    const float T = __builtin_fmaf(x.imax, __builtin_fabsf(b), __builtin_fmaf(x.jmax, __builtin_fabsf(c), __builtin_fabsf(a)));
+    const float slop = __builtin_fmaf(T, 12.0f * 0x1p-24f, x.slop0);
+    const float up = (hc - x.Lc) + __builtin_fmaf(x.di, __builtin_fabsf(b - x.gu), __builtin_fmaf(x.dj, __builtin_fabsf(c - x.gv), slop));
+    const float um = (-hc - x.Lc) + __builtin_fmaf(x.di, __builtin_fabsf(b + x.gu), __builtin_fmaf(x.dj, __builtin_fabsf(c + x.gv), slop));
+    return !(up < 0.0f && um < 0.0f);
+}
+
+// Tile lists (built per launch by pinhole_tiles_kernel): the same cull, done once for every run of `tile_cells` consecutive
+// work items, so that a group looks at the hundred-odd spheres of its one or two tiles and not at the whole table.
+// Record of tile t: tl[t * kTileRec] = number of spheres that passed, then the first kTileListCap of their indices, ascending.
+constexpr unsigned kTileRec = 128;
+constexpr unsigned kTileListCap = kTileRec - 1;
+
 // table: {A', B', C', -} per sphere in global memory, n_pad entries.  Returns the number of surviving spheres;
 // list[0 .. min(n, kCullCap)) = {A', B', C', sphere index bits}.  n > kCullCap: the list is incomplete, scan the table.
 // Four 64-sphere rows per trip, their loads issued together: the loop is a chain of L2 round trips otherwise.
-__device__ __forceinline__ unsigned cull_group(const float4* table, unsigned n_pad, float ci, float cj, float lt, bool live, float4* list, unsigned lane)
+__device__ __forceinline__ unsigned cull_table(const float4* table, unsigned n_pad, const CullBox& x, float4* list, unsigned lane)
 {
-    const float inf = __builtin_inff();
-    const float imin = wave_min(live ? ci : inf), imax = wave_max(live ? ci : -inf);
-    const float jmin = wave_min(live ? cj : inf), jmax = wave_max(live ? cj : -inf);
-    const float lmin = wave_min(live ? lt : inf);
-    if (!(imin <= imax)) return 0;  // no live slot in this group
-    // cell indices are integers below 2^24: sums, differences and halves are exact
-    const float ic = 0.5f * (imin + imax), di = 0.5f * (imax - imin), jc = 0.5f * (jmin + jmax), dj = 0.5f * (jmax - jmin);
     unsigned n = 0;
     constexpr int kRows = 4;
     for (unsigned base = 0; base < n_pad; base += 64u * kRows) {
         float4 e[kRows];
 #pragma unroll
-        for (int u = 0; u < kRows; ++u) {
-            const unsigned k = base + 64u * (unsigned)u + lane;
-            e[u] = table[k < n_pad ? k : n_pad - 1u];
+        for (int r = 0; r < kRows; ++r) {
+            const unsigned k = base + 64u * (unsigned)r + lane;
+            e[r] = table[k < n_pad ? k : n_pad - 1u];
         }
 #pragma unroll
-        for (int u = 0; u < kRows; ++u) {
-            const unsigned k = base + 64u * (unsigned)u + lane;
-            const float a = e[u].x, b = e[u].y, c = e[u].z;
-            const float fa = __builtin_fabsf(a), fb = __builtin_fabsf(b), fc = __builtin_fabsf(c);
-            const float hc = __builtin_fmaf(ic, b, __builtin_fmaf(jc, c, a));
-            float U = __builtin_fmaf(di, fb, __builtin_fmaf(dj, fc, __builtin_fabsf(hc)));
-            const float T = __builtin_fmaf(imax, fb, __builtin_fmaf(jmax, fc, fa));
-            U = __builtin_fmaf(T, 0x1p-21f, U);
-            const bool pass = k < n_pad && !(U * (1.0f + 0x1p-20f) < lmin);
+        for (int r = 0; r < kRows; ++r) {
+            const unsigned k = base + 64u * (unsigned)r + lane;
+            const bool pass = k < n_pad && cull_pass(x, e[r].x, e[r].y, e[r].z);
             const unsigned long long mask = __ballot(pass);
             if (mask) {
                 const unsigned pos = n + mbcnt64(mask);
-                if (pass && pos < kCullCap) list[pos] = make_float4(a, b, c, __uint_as_float(k));
+                if (pass && pos < kCullCap) list[pos] = make_float4(e[r].x, e[r].y, e[r].z, __uint_as_float(k));
                 n += (unsigned)__builtin_popcountll(mask);
             }
         }
     }
     return n;
+}
+
+// The same over the lists of tiles t0 .. t1 (at most two).  false: a tile's list is incomplete, the caller scans the table.
+// A sphere listed by both tiles is copied twice; its candidates are confirmed twice with the same key, which changes nothing.
+__device__ __forceinline__ bool cull_tiles(const float4* table, const uint32_t* tl, unsigned t0, unsigned t1, const CullBox& x, float4* list, unsigned lane, unsigned& n_out)
+{
+    unsigned n = 0;
+    for (unsigned t = t0; t <= t1; ++t) {
+        const uint32_t* rec = tl + (size_t)t * kTileRec;
+        const unsigned cnt = __builtin_amdgcn_readfirstlane(rec[0]);
+        if (cnt > kTileListCap) return false;
+        const unsigned k0 = lane < cnt ? rec[1u + lane] : 0u, k1 = lane + 64u < cnt ? rec[65u + lane] : 0u;
+        const float4 e0 = table[k0], e1 = table[k1];
+        const bool p0 = lane < cnt && cull_pass(x, e0.x, e0.y, e0.z), p1 = lane + 64u < cnt && cull_pass(x, e1.x, e1.y, e1.z);
+        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+        const unsigned pos0 = n + mbcnt64(m0);
+        if (p0 && pos0 < kCullCap) list[pos0] = make_float4(e0.x, e0.y, e0.z, __uint_as_float(k0));
+        n += (unsigned)__builtin_popcountll(m0);
+        const unsigned pos1 = n + mbcnt64(m1);
+        if (p1 && pos1 < kCullCap) list[pos1] = make_float4(e1.x, e1.y, e1.z, __uint_as_float(k1));
+        n += (unsigned)__builtin_popcountll(m1);
+    }
+    n_out = n;
+    return true;
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// The cull of one slot group: ci / cj the lanes' cell indices, m their work items (for the tile lists; tl == nullptr: none).
+__device__ __forceinline__ unsigned cull_group(const float4* table, unsigned n_pad, const uint32_t* tl, unsigned tile_shift, const CullGeom& q, float ci, float cj,
+                                               uint32_t m, bool live, float4* list, unsigned lane)
+{
+    const float inf = __builtin_inff();
+    const float imin = wave_min(live ? ci : inf), imax = wave_max(live ? ci : -inf);
+    const float jmin = wave_min(live ? cj : inf), jmax = wave_max(live ? cj : -inf);
+    if (!(imin <= imax)) return 0;  // no live slot in this group
+    const CullBox x = cull_box(q, imin, imax, jmin, jmax);
+    if (tl) {
+        const unsigned t0 = __builtin_amdgcn_readfirstlane(wave_min_u32(live ? m : 0xffffffffu) >> tile_shift);
+        const unsigned t1 = __builtin_amdgcn_readfirstlane(wave_max_u32(live ? m : 0u) >> tile_shift);
+        unsigned n = 0;
+        if (t1 - t0 <= 1u && cull_tiles(table, tl, t0, t1, x, list, lane, n)) return n;
+    }
+    return cull_table(table, n_pad, x, list, lane);
 }
 
 // The primary scan of slot group r over its cull list: same expression, same threshold as the full-table filter had

@@ -131,6 +131,8 @@ struct TraceParams {
     float4* prim_table; // {A, B, C, 0} / sK per sphere, rebuilt per launch; read by the per-wave cull
     uint32_t bvh_lds_nodes;  // pinhole kernel: the first this-many BvhNodes are copied into LDS (set by launch_pinhole)
     uint32_t grid_mode;      // pinhole kernel: 0 no grid, 1 grid in LDS, 2 grid in global memory (pinhole_grid_mode, set before sizing)
+    uint32_t tile_shift;     // pinhole kernel: a cull tile is 2^tile_shift consecutive work items (pinhole_tile_shift); 0 = no tile lists
+    uint32_t* tile_lists;    // set by launch_pinhole: behind the shared-origin table in the same buffer
 };
 
 // Work counters of the Projector kernel: batch b of 64 units belongs to counter b % kUnitCounters; one 128-byte line each.
@@ -155,10 +157,11 @@ hipError_t noalloc_scratch_address(void** out);
 
 // Launches the trace kernel on `stream` of `device` (the current device; per-device launch state is keyed by it).
 hipError_t launch_trace(const TraceParams& p, int n_cu, int device, hipStream_t stream);
-// Shared-origin (Projector) specialisation. secq must hold pinhole_secq_bytes(), prim_table pinhole_table_bytes().
+// Shared-origin (Projector) specialisation. secq must hold pinhole_secq_bytes(), prim_table pinhole_table_bytes() (table + tile lists).
 hipError_t launch_pinhole(const TraceParams& p, int n_cu, int device, hipStream_t stream);
 size_t pinhole_secq_bytes(const TraceParams& p, int n_cu);
 size_t pinhole_table_bytes(const TraceParams& p);
+uint32_t pinhole_tile_shift(const TraceParams& p);  // cull tiles for this launch (TraceParams::tile_shift), 0 when they would not pay
 uint32_t pinhole_grid_mode(const TraceParams& p);  // how this launch's continuing rays find their spheres (TraceParams::grid_mode)
 hipError_t launch_finalize(const unsigned long long* fb_q, float* fb, uint32_t* seg_count, uint64_t n_cells, uint32_t spp, hipStream_t stream);
 

@@ -75,6 +75,42 @@ __global__ void pinhole_table_kernel(const TraceParams p, float4* table)
     if (k < p.sc.n_sph_pad) table[k] = pinhole_entry(p, k, f3(p.gen.a[0], p.gen.a[1], p.gen.a[2]));
 }
 
+// The tile lists of a launch (rt_device.h cull_tiles): one wave per tile culls the table against the tile's box of cells.
+__global__ __launch_bounds__(256) void pinhole_tiles_kernel(const TraceParams p, const float4* table, uint32_t* tl)
+{
+    const unsigned lane = lane_id();
+    const unsigned t = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const unsigned tile_cells = 1u << p.tile_shift;
+    const unsigned n_tiles = (p.cell_count + tile_cells - 1u) >> p.tile_shift;
+    if (t >= n_tiles) return;
+    const uint32_t m0 = t << p.tile_shift;
+    const uint32_t m1 = p.cell_count - m0 < tile_cells ? p.cell_count : m0 + tile_cells;
+    const float inf = __builtin_inff();
+    float imin = inf, imax = -inf, jmin = inf, jmax = -inf;
+    for (uint32_t m = m0 + lane; m < m1; m += 64u) {
+        uint32_t i, j;
+        cell_indices(p, m, i, j);
+        imin = __builtin_fminf(imin, (float)i);
+        imax = __builtin_fmaxf(imax, (float)i);
+        jmin = __builtin_fminf(jmin, (float)j);
+        jmax = __builtin_fmaxf(jmax, (float)j);
+    }
+    const CullBox x = cull_box(cull_geom(p.gen), wave_min(imin), wave_max(imax), wave_min(jmin), wave_max(jmax));
+    uint32_t* rec = tl + (size_t)t * kTileRec;
+    const unsigned n_pad = p.sc.n_sph_pad;
+    unsigned n = 0;
+    for (unsigned base = 0; base < n_pad; base += 64u) {
+        const unsigned k = base + lane;
+        const float4 e = table[k < n_pad ? k : n_pad - 1u];
+        const bool pass = k < n_pad && cull_pass(x, e.x, e.y, e.z);
+        const unsigned long long mask = __ballot(pass);
+        const unsigned pos = n + mbcnt64(mask);
+        if (pass && pos < kTileListCap) rec[1u + pos] = k;
+        n += (unsigned)__builtin_popcountll(mask);
+    }
+    if (lane == 0) rec[0] = n;
+}
+
 // Constants of the general filter (FLAVOR 0 of scan_step) for slot r.
 template <int R>
 __device__ __forceinline__ void general_consts(ScanConsts<R>& c, int r, F3 o, F3 d, float a, bool live, const DevScene& sc)
@@ -298,11 +334,21 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (cull_stale[r]) {
-                    n_cull[r] = cull_group(p.prim_table, n_pad, c.ci[r], c.cj[r], c.lt[r], live[r], cull_all[wave][r], lane);
+                    n_cull[r] = cull_group(p.prim_table, n_pad, p.tile_lists, p.tile_shift, cull_geom_from_kernarg(offsetof(TraceParams, gen)), c.ci[r], c.cj[r], um[r], live[r],
+                                           cull_all[wave][r], lane);
                     cull_stale[r] = false;
+#if RT_DBG_WALK == 10
+                    if (lane == 0) my_dbg += n_cull[r];
+#endif
+#if RT_DBG_WALK == 11
+                    if (lane == 0) ++my_dbg;
+#endif
                 }
                 listed &= n_cull[r] <= kCullCap;
             }
+#if RT_DBG_WALK == 9
+            if (lane == 0 && !listed) ++my_dbg;
+#endif
             if (listed) {
                 wave_lds_sync();
 #pragma unroll
@@ -568,7 +614,20 @@ uint32_t pinhole_grid_mode(const TraceParams& p)
     return grid_mode_of(p, fa.sharedSizeBytes);
 }
 
-size_t pinhole_table_bytes(const TraceParams& p) { return (size_t)p.sc.n_sph_pad * sizeof(float4); }
+// Tiles pay once the table is longer than the couple of rows a tile's list costs; at most 2^16 of them per launch.
+uint32_t pinhole_tile_shift(const TraceParams& p)
+{
+    if (p.sc.n_sph_pad <= 256 || getenv("RT_HIP_NO_TILES")) return 0;
+    uint32_t s = 6;
+    while ((((uint64_t)p.cell_count + (1ull << s) - 1) >> s) > 65536ull) ++s;
+    return s;
+}
+static size_t tile_list_bytes(const TraceParams& p)
+{
+    return p.tile_shift ? (size_t)(((uint64_t)p.cell_count + (1ull << p.tile_shift) - 1) >> p.tile_shift) * kTileRec * sizeof(uint32_t) : 0;
+}
+
+size_t pinhole_table_bytes(const TraceParams& p) { return (size_t)p.sc.n_sph_pad * sizeof(float4) + tile_list_bytes(p); }
 
 template <bool CX>
 static hipError_t launch_pinhole_t(const TraceParams& p_in, int n_cu, int device, hipStream_t stream)
@@ -589,9 +648,16 @@ static hipError_t launch_pinhole_t(const TraceParams& p_in, int n_cu, int device
         attr_set = true;
     }
     // the shared-origin table of this launch's generator: read by the per-wave cull only
+    p.tile_lists = nullptr;
     if (p.sc.n_sph_pad) {
         hipLaunchKernelGGL(pinhole_table_kernel, dim3((p.sc.n_sph_pad + 255) / 256), dim3(256), 0, stream, p, p.prim_table);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+        if (p.tile_shift && p.cell_count) {
+            p.tile_lists = reinterpret_cast<uint32_t*>(p.prim_table + p.sc.n_sph_pad);
+            const unsigned n_tiles = (unsigned)(((uint64_t)p.cell_count + (1ull << p.tile_shift) - 1) >> p.tile_shift);
+            hipLaunchKernelGGL(pinhole_tiles_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, stream, p, p.prim_table, p.tile_lists);
+            if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+        }
     }
     if (stream_mode(p)) {
         hipLaunchKernelGGL((pinhole_kernel<kR, true, CX>), dim3(grid), dim3(kPinThreads), dyn_lds(p), stream, p);
