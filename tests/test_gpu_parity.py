@@ -973,3 +973,38 @@ direction = [0.0, 0.0, 1.0]
     b = engine.Scene(objs).simulate_rays_raw(st, rays=rays[:3000], seed=4)
     assert np.array_equal(a[1], b[1])
     assert_records_equal(a[2], b[2], "box grid scan modes")
+
+
+@pytest.mark.parametrize("n_spheres,spp,w,h,crowd", [(400, 8, 96, 70, 0), (400, 13, 64, 50, 0), (1500, 5, 70, 64, 0), (700, 9, 40, 200, 300)])
+def test_cull_tile_lists_change_nothing(engine, n_spheres, spp, w, h, crowd):
+    """The per-launch tile lists of the primary cull only narrow which spheres a group looks at: the same
+    frame with RT_HIP_NO_TILES=1 (every group culls the whole table) is bit-identical, and both are the oracle's frame.
+    Cases: whole and ragged sample blocks (lanes of a group drift apart, groups then span several tiles), strided cell
+    ranges (a tile's cells are not neighbours), tall grids (a tile wraps from one column of cells to the next) and a crowd
+    of spheres in front of the projector (tile lists overflow, those groups fall back to the table)."""
+    objs = random_scene(n_spheres, 1, seed=n_spheres + spp, extent=(30.0, 18.0, 30.0))
+    if crowd:
+        rng = np.random.default_rng(5)
+        extra = np.zeros(crowd, abi.OBJECT_DTYPE)
+        extra["shape"] = abi.RT_SHAPE_SPHERE
+        extra["position"] = (rng.normal(size=(crowd, 3)) * (2.0, 2.0, 0.5) + (0.0, 1.0, -40.0)).astype(np.float32)
+        extra["shape_param"][:, 0] = rng.uniform(0.3, 1.2, crowd).astype(np.float32)
+        extra["material_kind"] = abi.RT_MAT_MIRROR
+        objs = np.concatenate([objs, extra])
+    gen = projector((0.0, 1.0, -70.0), (-32.0, -19.0, -30.0), (64.0, 0.0, 0.0), (0.0, 38.0, 0.0), w, h, 1.0)
+    st = SimulationSettingsConfig(40.0, 4)
+    sc = engine.Scene(objs)
+    osc = ob.OracleScene(objs)
+    n = w * h
+    for begin, step in ((0, 1), (n // 5, 3)):
+        count = (n - begin + step - 1) // step
+        got = sc.render(gen, spp, st, seed=31, cell_begin=begin, cell_count=count, cell_step=step)
+        os.environ["RT_HIP_NO_TILES"] = "1"
+        try:
+            plain = sc.render(gen, spp, st, seed=31, cell_begin=begin, cell_count=count, cell_step=step)
+        finally:
+            del os.environ["RT_HIP_NO_TILES"]
+        want = osc.render(gen, spp, 40.0, 4, seed=31, cell_begin=begin, cell_count=count, cell_step=step, threads=8)
+        for a, b, c in zip(got[:4], plain[:4], want[:4]):
+            assert np.array_equal(a, b) and np.array_equal(a, c)
+        assert got[4] == plain[4] == want[4]
