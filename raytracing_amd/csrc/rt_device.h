@@ -444,25 +444,56 @@ __device__ __forceinline__ CullGeom cull_geom(const DevGen& g)
     q.M = __builtin_sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) * 1.001f;
     return q;
 }
-// The same from the kernel's argument block (TraceParams is the kernel's only argument, so the block starts with it), read
-// where it is needed: a cull happens once per eight steps, and thirteen more scalar registers held across the whole loop
-// push the grid's constants out of theirs (reloaded a hundred times per walk: 8 % of a C2 frame, measured).
-__device__ __forceinline__ CullGeom cull_geom_from_kernarg(size_t gen_offset)
+// A member of the kernel's argument block (TraceParams is the first argument of every kernel here, so the block starts with
+// it), read where it is needed rather than held in scalar registers for the whole kernel.  The optimiser would hoist such loads
+// out of the main loop, and the hundred-odd scalars this kernel keeps live already spill; each newcomer pushed the grid's
+// constants out of their registers (reloaded a hundred times per walk: 8 % of a C2 frame, measured twice).  The empty asm
+// makes the address opaque, so the loads stay where they are written: two or three s_load per use.
+#define RT_KERNARG_PTR(T, name, offset)                                                                                                    \
+    const char __attribute__((address_space(4)))* name##_base = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr(); \
+    asm volatile("" : "+s"(name##_base));                                                                                                  \
+    const T __attribute__((address_space(4)))* name = reinterpret_cast<const T __attribute__((address_space(4)))*>(name##_base + (offset))
+// (member by member: a whole-struct copy goes through private memory)
+__device__ __forceinline__ DevGen kernarg_gen(size_t offset)
 {
-    const char __attribute__((address_space(4)))* kp = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));  // not loop-invariant as far as the optimiser can tell
-    const DevGen __attribute__((address_space(4)))* gp = reinterpret_cast<const DevGen __attribute__((address_space(4)))*>(kp + gen_offset);
+    RT_KERNARG_PTR(DevGen, gp, offset);
     DevGen g;
+    g.kind = gp->kind;
     g.count_u = gp->count_u;
     g.count_v = gp->count_v;
+    g.current_ior = gp->current_ior;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         g.a[k] = gp->a[k];
         g.corner[k] = gp->corner[k];
         g.u_step[k] = gp->u_step[k];
         g.v_step[k] = gp->v_step[k];
+        g.dir_n[k] = gp->dir_n[k];
     }
-    return cull_geom(g);
+    return g;
+}
+__device__ __forceinline__ DevGrid kernarg_grid(size_t offset)
+{
+    RT_KERNARG_PTR(DevGrid, gp, offset);
+    DevGrid g;
+    g.cells = gp->cells;
+    g.items = gp->items;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g.lo[k] = gp->lo[k];
+        g.hi[k] = gp->hi[k];
+        g.dim[k] = gp->dim[k];
+        g.centre[k] = gp->centre[k];
+    }
+    g.cell = gp->cell;
+    g.inv_cell = gp->inv_cell;
+    g.radius = gp->radius;
+    g.origin_r2 = gp->origin_r2;
+    g.slack_k = gp->slack_k;
+    g.n_cells = gp->n_cells;
+    g.n_items = gp->n_items;
+    g.enabled = gp->enabled;
+    return g;
 }
 
 __device__ __forceinline__ float sgpr(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }

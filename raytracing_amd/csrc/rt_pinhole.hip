@@ -150,7 +150,8 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
     __shared__ float4 cull_all[kPinThreads / 64][R][kCullCap];  // per wave and slot group: the spheres its current cells can reach
     // Per work unit: the primary ray's direction, its cell indices and the filter threshold.  Every sample of a unit starts with the
     // same ray (the reference's Projector has no jitter), so these are worked out when the unit is dealt and read back each step.
-    __shared__ float unit_ray_all[kPinThreads / 64][R][6][64];
+    // Rows 6 / 7: the scan's result for that ray (the 64-bit best key), found by the unit's first sample and reused by the others.
+    __shared__ float unit_ray_all[kPinThreads / 64][R][8][64];
 
     const unsigned lane = lane_id();
     const unsigned wave = threadIdx.x >> 6;
@@ -231,6 +232,9 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
         float rior[R];
         uint32_t rm[R], rsample[R], rb[R];
         bool live[R], scan_live[R];
+        bool fresh[R];  // primary step: this lane's unit is at its first sample, so its ray has not been scanned yet
+#pragma unroll
+        for (int r = 0; r < R; ++r) fresh[r] = false;
         unsigned head = 0, tail = 0;
 
         if (!do_sec) {
@@ -324,17 +328,24 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
                 c.ci[r] = live[r] ? ur[3][lane] : 0.0f;
                 c.cj[r] = live[r] ? ur[4][lane] : 0.0f;
                 c.lt[r] = live[r] ? ur[5][lane] : __builtin_inff();  // dead slots are masked by `live`
+                fresh[r] = live[r] && usegs[r] == 0u;  // usegs counts the unit's primary segments
             }
             wave_lds_sync();
             if (true) { RT_T1(2) }
             if (true) { RT_T1(12) }
             RT_T0(4)  // region 4: cull lists and the primary scan over them
             // groups whose cells changed rebuild their list (once per unit_samples steps when the units are of equal length)
-            bool listed = true;
+            bool listed = true, any_fresh = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) any_fresh |= __ballot(fresh[r]) != 0ull;
+            // Every sample of a unit starts with the same ray and therefore finds the same closest scan-path entry: only the unit's
+            // first sample looks for it (the others pick the key up below).  Units of equal length are dealt together, so seven
+            // steps of eight skip the scan altogether.
+            if (any_fresh) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (cull_stale[r]) {
-                    n_cull[r] = cull_group(p.prim_table, n_pad, p.tile_lists, p.tile_shift, cull_geom_from_kernarg(offsetof(TraceParams, gen)), c.ci[r], c.cj[r], um[r], live[r],
+                    n_cull[r] = cull_group(p.prim_table, n_pad, p.tile_lists, p.tile_shift, cull_geom(kernarg_gen(offsetof(TraceParams, gen))), c.ci[r], c.cj[r], um[r], live[r],
                                            cull_all[wave][r], lane);
                     cull_stale[r] = false;
 #if RT_DBG_WALK == 10
@@ -352,12 +363,13 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
             if (listed) {
                 wave_lds_sync();
 #pragma unroll
-                for (int r = 0; r < R; ++r) scan_cull_list<R>(cull_all[wave][r], n_cull[r], r, c.ci[r], c.cj[r], c.lt[r], live[r], w, sc, head, tail, lane);
+                for (int r = 0; r < R; ++r) scan_cull_list<R>(cull_all[wave][r], n_cull[r], r, c.ci[r], c.cj[r], c.lt[r], fresh[r], w, sc, head, tail, lane);
             } else {
                 // more spheres in reach than a list holds (the origin sits inside a crowd): these rays take the general filter
 #pragma unroll
-                for (int r = 0; r < R; ++r) general_consts<R>(c, r, ro[r], rd[r], dot(rd[r], rd[r]), live[r], sc);
+                for (int r = 0; r < R; ++r) general_consts<R>(c, r, ro[r], rd[r], dot(rd[r], rd[r]), fresh[r], sc);
                 general_scan<R, STREAM>(gm == 1, tileG, n_pad, stage, c, w, sc, head, tail, lane);
+            }
             }
             RT_T1(4)
         } else {
@@ -396,18 +408,19 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
             RT_T0(5)  // region 5: grid walk / table scan of the continuing rays
             // the grid serves every ray that starts within its error budget; a wave with one that does not scans the table
             bool walk = gm != 0;
+            const DevGrid gw = kernarg_grid(offsetof(TraceParams, sc) + offsetof(DevScene, grid));  // this step's copy of the grid's constants
             if (walk) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) walk &= __ballot(scan_live[r] && !grid_admits(grid, ro[r], rd[r])) == 0ull;
+                for (int r = 0; r < R; ++r) walk &= __ballot(scan_live[r] && !grid_admits(gw, ro[r], rd[r])) == 0ull;
             }
             if (walk) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const float a = dot(rd[r], rd[r]);
                     if constexpr (STREAM)  // grid mode 2
-                        grid_walk<R>(grid, grid.cells, grid.items, sc.sph_exact, ro[r], rd[r], a, scan_live[r], r * 64u, w, sc, head, tail, lane, my_dbg);
+                        grid_walk<R>(gw, gw.cells, gw.items, sc.sph_exact, ro[r], rd[r], a, scan_live[r], r * 64u, w, sc, head, tail, lane, my_dbg);
                     else  // grid mode 1
-                        grid_walk<R>(grid, (LdsU32*)grid_lds, (LdsU16*)(grid_lds + grid.n_cells), (LdsGV4*)tiles, ro[r], rd[r], a, scan_live[r], r * 64u, w, sc,
+                        grid_walk<R>(gw, (LdsU32*)grid_lds, (LdsU16*)(grid_lds + gw.n_cells), (LdsGV4*)tiles, ro[r], rd[r], a, scan_live[r], r * 64u, w, sc,
                                      head, tail, lane, my_dbg);
                 }
             } else {
@@ -423,6 +436,20 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
         wave_lds_sync();
         if (tail != head) confirm_batch<R>(w, sc, head, tail - head, lane);
         wave_lds_sync();
+        if (!do_sec) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float (*ur)[64] = unit_ray_all[wave][r];
+                const unsigned slot = r * 64 + lane;
+                if (fresh[r]) {
+                    const unsigned long long k = w.best[slot];
+                    ur[6][lane] = __uint_as_float((unsigned)k);
+                    ur[7][lane] = __uint_as_float((unsigned)(k >> 32));
+                } else if (live[r]) {
+                    w.best[slot] = ((unsigned long long)__float_as_uint(ur[7][lane]) << 32) | __float_as_uint(ur[6][lane]);
+                }
+            }
+        }
         RT_T1(6)
         RT_T0(7)  // regions 7 / 8: resolve, shade, accumulate, ring push of a primary / continuing step
         RT_T0(8)
