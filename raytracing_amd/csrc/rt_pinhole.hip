@@ -32,6 +32,9 @@ namespace {
 // 512 threads: 8 waves share the LDS tables, 2 blocks per CU = 4 waves per SIMD at 128 VGPRs (with spills).  Measured alternatives
 // (DESIGN.md §4.5): 384 threads / 3 waves per SIMD / 168 VGPRs and 256 threads / 2 waves per SIMD / 187 VGPRs without spills are
 // both slower (C2 frame 9.9 ms and 7.7 ms against 6.0 ms): the grid walk lives on occupancy, not on registers.
+#ifndef RT_PRIMARY_REUSE
+#define RT_PRIMARY_REUSE 0
+#endif
 #ifndef RT_PIN_THREADS
 #define RT_PIN_THREADS 512
 #define RT_PIN_WAVES 4
@@ -150,8 +153,8 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
     __shared__ float4 cull_all[kPinThreads / 64][R][kCullCap];  // per wave and slot group: the spheres its current cells can reach
     // Per work unit: the primary ray's direction, its cell indices and the filter threshold.  Every sample of a unit starts with the
     // same ray (the reference's Projector has no jitter), so these are worked out when the unit is dealt and read back each step.
-    // Rows 6 / 7: the scan's result for that ray (the 64-bit best key), found by the unit's first sample and reused by the others.
-    __shared__ float unit_ray_all[kPinThreads / 64][R][8][64];
+    // (rows 6 / 7, RT_PRIMARY_REUSE builds only: the scan's result for that ray, the 64-bit best key)
+    __shared__ float unit_ray_all[kPinThreads / 64][R][RT_PRIMARY_REUSE ? 8 : 6][64];
 
     const unsigned lane = lane_id();
     const unsigned wave = threadIdx.x >> 6;
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
                 c.ci[r] = live[r] ? ur[3][lane] : 0.0f;
                 c.cj[r] = live[r] ? ur[4][lane] : 0.0f;
                 c.lt[r] = live[r] ? ur[5][lane] : __builtin_inff();  // dead slots are masked by `live`
-                fresh[r] = live[r] && usegs[r] == 0u;  // usegs counts the unit's primary segments
+                fresh[r] = live[r] && (!RT_PRIMARY_REUSE || usegs[r] == 0u);  // usegs counts the unit's primary segments
             }
             wave_lds_sync();
             if (true) { RT_T1(2) }
@@ -338,9 +341,9 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
             bool listed = true, any_fresh = false;
 #pragma unroll
             for (int r = 0; r < R; ++r) any_fresh |= __ballot(fresh[r]) != 0ull;
-            // Every sample of a unit starts with the same ray and therefore finds the same closest scan-path entry: only the unit's
-            // first sample looks for it (the others pick the key up below).  Units of equal length are dealt together, so seven
-            // steps of eight skip the scan altogether.
+            // -DRT_PRIMARY_REUSE=1 (measured, not shipped: C2 -2 %, C4 -5 %): every sample of a unit starts with the same ray and
+            // therefore finds the same closest scan-path entry, so only the unit's first sample would have to look for it and the
+            // others could pick its key up below.  The shipped kernel searches for every sample's ray: `fresh` is `live`.
             if (any_fresh) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
         wave_lds_sync();
         if (tail != head) confirm_batch<R>(w, sc, head, tail - head, lane);
         wave_lds_sync();
-        if (!do_sec) {
+        if (RT_PRIMARY_REUSE && !do_sec) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 float (*ur)[64] = unit_ray_all[wave][r];
@@ -456,6 +459,7 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
 
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+            RT_T0(13)  // regions 13 / 14 / 15: resolve + shade, per-cell sums, ring push (primary steps only)
             bool push = false, fl = false;
             uint32_t fcell = 0;
             unsigned long long fx = 0, fy = 0, fz = 0, fsegs = 0;
@@ -527,8 +531,12 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
                     fsegs = b;
                 }
             }
+            if (!do_sec) { RT_T1(13) }
+            RT_T0(14)
             // per-cell sums: neighbouring lanes of one cell are combined first (rt_device.h flush_cells)
             flush_cells(p.fb_q, fl, fcell, fx, fy, fz, fsegs, reinterpret_cast<uint32_t*>(&w.stash[0][0]), lane);
+            if (!do_sec) { RT_T1(14) }
+            RT_T0(15)
             // append continuing rays to the ring (wave-uniform control flow)
             const unsigned long long pm = __ballot(push);
             if (pm) {
@@ -547,6 +555,7 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
                 }
                 sec_count += (unsigned)__builtin_popcountll(pm);
             }
+            if (!do_sec) { RT_T1(15) }
         }
         if (!do_sec) { RT_T1(7) } else { RT_T1(8) }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
