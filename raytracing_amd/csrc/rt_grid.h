@@ -16,7 +16,7 @@
 #include "rt_device.h"
 
 #ifndef RT_WALK_ITEMS
-#define RT_WALK_ITEMS 4
+#define RT_WALK_ITEMS 2  // measured with cells of 0.8 x the mean spacing: 1 / 2 / 3 / 4 entries per pass = 3.97 / 3.76 / - / 4.00 ms per C2 frame
 #endif
 
 namespace rt {

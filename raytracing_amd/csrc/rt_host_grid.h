@@ -22,7 +22,7 @@
 #include "rt_internal.h"
 
 #ifndef RT_GRID_CELL_SCALE
-#define RT_GRID_CELL_SCALE 1.0  // cell edge in units of cbrt(volume / entries); A/B builds only
+#define RT_GRID_CELL_SCALE 0.8  // cell edge in units of cbrt(volume / entries); C2 frame at 0.65 / 0.7 / 0.8 / 0.9 / 1.0 (two entries per pass): - / 3.84 / 3.76 / 3.84 / 3.93 ms
 #endif
 
 namespace rt {
@@ -79,7 +79,7 @@ inline GridHost build_grid(const std::vector<float4>& sph_exact, const std::vect
         ext[a] = hi[a] - lo[a];
         vol *= ext[a];
     }
-    double cs = RT_GRID_CELL_SCALE * std::cbrt(vol / (double)n);  // measured on C2: 1.25x / 1.5x larger cells cost 7 % / 12 % of the frame  // (0.6x .. 1.0x: within 2 %)
+    double cs = RT_GRID_CELL_SCALE * std::cbrt(vol / (double)n);
     // every cell at least as wide as the typical inflated sphere box would make a sphere span 8+ cells: keep cells >= 2 E
     cs = std::max(cs, 2.0 * E);
     uint32_t dim[3];
