@@ -185,7 +185,7 @@ def main():
 
         value = segs_all * args.steps / elapsed_max / 1e6
         launches = len(frame.launches)
-        kernel_ms = render_ms / launches  # average duration of one launch of the dominant kernel (finalize + memsets: < 0.5 %)
+        kernel_ms = render_ms / launches  # average duration of one launch of the dominant kernel (+ the table, tile-list and finalize kernels and memsets beside it: 2 % on C2, 0.4 % on C4)
         algorithmic = segs_local * FLOP_PER_TEST * n_sph / (render_ms * 1e-3) / 1e12
         pmc = {}
         if os.path.exists(PMC):
