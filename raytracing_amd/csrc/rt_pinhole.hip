@@ -650,12 +650,15 @@ uint32_t pinhole_grid_mode(const TraceParams& p)
     return grid_mode_of(p, fa.sharedSizeBytes);
 }
 
-// Tiles pay once the table is longer than the couple of rows a tile's list costs; at most 2^16 of them per launch.
+// Tiles pay once the table is longer than the couple of rows a tile's list costs.  A tile should span about 64 generator cells:
+// 64 work items of a contiguous range, fewer (down to 8) when the launch takes every cell_step-th cell, as the ranks of a sharded
+// frame do -- a tile's box, and with it its list, grows with the span.  At most 2^18 tiles (128 MB of lists) per launch.
 uint32_t pinhole_tile_shift(const TraceParams& p)
 {
     if (p.sc.n_sph_pad <= 256 || getenv("RT_HIP_NO_TILES")) return 0;
     uint32_t s = 6;
-    while ((((uint64_t)p.cell_count + (1ull << s) - 1) >> s) > 65536ull) ++s;
+    for (uint64_t step = p.cell_step; step > 1 && s > 3; step >>= 1) --s;
+    while ((((uint64_t)p.cell_count + (1ull << s) - 1) >> s) > (1ull << 18)) ++s;
     return s;
 }
 static size_t tile_list_bytes(const TraceParams& p)
