@@ -280,8 +280,14 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
                     if (need_unit && mbcnt64(need) < take) {
                         unsigned long long unit = base + mbcnt64(need);
                         {
-                            uint32_t m = (uint32_t)(unit / p.units_per_cell);
-                            uint32_t k = (uint32_t)(unit - (unsigned long long)m * p.units_per_cell);
+                            uint32_t m, k;
+                            if ((total_units >> 32) == 0) {  // (a 64-bit division costs a few hundred instructions)
+                                m = (uint32_t)unit / p.units_per_cell;
+                                k = (uint32_t)unit - m * p.units_per_cell;
+                            } else {
+                                m = (uint32_t)(unit / p.units_per_cell);
+                                k = (uint32_t)(unit - (unsigned long long)m * p.units_per_cell);
+                            }
                             um[r] = m;
                             usample[r] = k * p.unit_samples;
                             uint32_t e = usample[r] + p.unit_samples;
