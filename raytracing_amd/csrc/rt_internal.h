@@ -140,7 +140,7 @@ constexpr unsigned kUnitCounters = 32;
 constexpr unsigned kUnitCounterStride = 16;  // in 64-bit words
 constexpr size_t kUnitCounterBytes = (size_t)kUnitCounters * kUnitCounterStride * sizeof(unsigned long long);  // 4,096
 
-constexpr unsigned kSecCap = 256;    // entries per wave ring (a primary step adds <= 128 to a residue < 128)
+constexpr unsigned kSecCap = 256;    // entries per wave ring (a primary step adds <= 64 R to a residue < 64 R; R <= 2 rays per lane)
 constexpr unsigned kSecFields = 10;  // o.xyz d.xyz ior cell sample bounce
 
 // ---- fixed workspace of rt_hip_render_dev_noalloc (rt_scratch.hip): one static device array, carved into regions ----

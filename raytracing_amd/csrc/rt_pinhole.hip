@@ -29,9 +29,10 @@ namespace {
 #endif
 
 
-// 512 threads: 8 waves share the LDS tables, 2 blocks per CU = 4 waves per SIMD at 128 VGPRs (with spills).  Measured alternatives
-// (DESIGN.md §4.5): 384 threads / 3 waves per SIMD / 168 VGPRs and 256 threads / 2 waves per SIMD / 187 VGPRs without spills are
-// both slower (C2 frame 9.9 ms and 7.7 ms against 6.0 ms): the grid walk lives on occupancy, not on registers.
+// 512 threads: 8 waves share the LDS tables, 2 blocks per CU = 4 waves per SIMD at 128 VGPRs (about ten of them spilled with one
+// ray per lane, RT_PIN_R = 1; 109 with two).  Measured alternatives (two rays per lane): 384 threads / 3 waves per
+// SIMD / 168 VGPRs and 256 threads / 2 waves per SIMD / 187 VGPRs without spills were both slower (C2 frame 9.9 ms and 7.7 ms
+// against 6.0 ms): the grid walk lives on occupancy, not on registers.
 #ifndef RT_PRIMARY_REUSE
 #define RT_PRIMARY_REUSE 0
 #endif
