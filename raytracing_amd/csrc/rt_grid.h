@@ -86,11 +86,10 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
     // start cell (clamped: the entry point may sit a rounding error outside) and the first boundary crossings
     const float ex = __builtin_fmaf(t0, d.x, o.x), ey = __builtin_fmaf(t0, d.y, o.y), ez = __builtin_fmaf(t0, d.z, o.z);
     const int dimx = (int)g.dim[0], dimy = (int)g.dim[1], dimz = (int)g.dim[2];
-    int cx = (int)__builtin_floorf((ex - g.lo[0]) * g.inv_cell), cy = (int)__builtin_floorf((ey - g.lo[1]) * g.inv_cell),
-        cz = (int)__builtin_floorf((ez - g.lo[2]) * g.inv_cell);
-    cx = cx < 0 ? 0 : (cx >= dimx ? dimx - 1 : cx);
-    cy = cy < 0 ? 0 : (cy >= dimy ? dimy - 1 : cy);
-    cz = cz < 0 ? 0 : (cz >= dimz ? dimz - 1 : cz);
+    // clamped as floats (fmax / fmin drop a NaN), so the conversion is defined for every lane, live or not
+    int cx = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf((ex - g.lo[0]) * g.inv_cell), 0.0f), (float)(dimx - 1));
+    int cy = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf((ey - g.lo[1]) * g.inv_cell), 0.0f), (float)(dimy - 1));
+    int cz = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf((ez - g.lo[2]) * g.inv_cell), 0.0f), (float)(dimz - 1));
     const int sx = d.x > 0.0f ? 1 : -1, sy = d.y > 0.0f ? 1 : -1, sz = d.z > 0.0f ? 1 : -1;
     float tmx = tdx < inf ? (g.lo[0] + (float)(cx + (sx > 0 ? 1 : 0)) * g.cell - o.x) * ivx : inf;
     float tmy = tdy < inf ? (g.lo[1] + (float)(cy + (sy > 0 ? 1 : 0)) * g.cell - o.y) * ivy : inf;
@@ -98,7 +97,15 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
 
     float bound = inf;  // upper bound of the t that will win, from spheres already queued
     unsigned k = 0, cnt = 0, start = 0;
-    bool first = true;  // the start cell's record has not been read yet
+    {
+        // The start cell's record, read here and not by a first pass that tests nothing (that pass was one in fourteen).
+        // Every lane reads (the indices are clamped, so the address is valid whatever the lane holds) and inactive lanes drop the
+        // result: with the load under `if (active)` this compiler (ROCm 7.2 clang, -O1 and -O3 alike) produced a kernel that lost
+        // hits on half of the fuzz cases; the two forms mean the same.
+        const unsigned rec = cells[((unsigned)cz * (unsigned)dimy + (unsigned)cy) * (unsigned)dimx + (unsigned)cx];
+        start = active ? rec & 0xfffffu : 0u;
+        cnt = active ? rec >> 20 : 0u;
+    }
 #if RT_DBG_WALK == 4
     if (lane == 0) ++dbg;
 #endif
@@ -113,6 +120,12 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
         bool pass[kWalkItems];
         unsigned jj[kWalkItems];
         const unsigned rem = active ? cnt - k : 0u;
+#if RT_DBG_WALK == 6
+        if (active && rem == 0u) ++dbg;  // lane-passes spent on a cell without entries (or on the start cell's record)
+#endif
+#if RT_DBG_WALK == 7
+        if (lane == 0 && __ballot(rem != 0u) == 0ull) ++dbg;  // passes in which no lane tests anything
+#endif
 #pragma unroll
         for (int u = 0; u < kWalkItems; ++u) {
             pass[u] = false;
@@ -152,25 +165,22 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
         }
         // once the cell is used up: stop, or step to the next cell and read its record
         if (active && k >= cnt) {
-            if (!first) {
-                const float texit = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
-                if (bound < texit - slack) {
-                    active = false;  // everything that can still win starts before texit - slack and has been seen
-                } else {
+            const float texit = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
+            if (bound < texit - slack) {
+                active = false;  // everything that can still win starts before texit - slack and has been seen
+            } else {
 #if RT_DBG_WALK == 5
-                    ++dbg;
+                ++dbg;
 #endif
-                    const bool stepx = tmx <= tmy && tmx <= tmz, stepy = !stepx && tmy <= tmz, stepz = !stepx && !stepy;
-                    cx += stepx ? sx : 0;
-                    cy += stepy ? sy : 0;
-                    cz += stepz ? sz : 0;
-                    tmx += stepx ? tdx : 0.0f;
-                    tmy += stepy ? tdy : 0.0f;
-                    tmz += stepz ? tdz : 0.0f;
-                    if ((unsigned)cx >= (unsigned)dimx || (unsigned)cy >= (unsigned)dimy || (unsigned)cz >= (unsigned)dimz) active = false;
-                }
+                const bool stepx = tmx <= tmy && tmx <= tmz, stepy = !stepx && tmy <= tmz, stepz = !stepx && !stepy;
+                cx += stepx ? sx : 0;
+                cy += stepy ? sy : 0;
+                cz += stepz ? sz : 0;
+                tmx += stepx ? tdx : 0.0f;
+                tmy += stepy ? tdy : 0.0f;
+                tmz += stepz ? tdz : 0.0f;
+                if ((unsigned)cx >= (unsigned)dimx || (unsigned)cy >= (unsigned)dimy || (unsigned)cz >= (unsigned)dimz) active = false;
             }
-            first = false;
             if (active) {
                 const unsigned rec = cells[((unsigned)cz * (unsigned)dimy + (unsigned)cy) * (unsigned)dimx + (unsigned)cx];
                 start = rec & 0xfffffu;
