@@ -665,6 +665,10 @@ uint32_t pinhole_tile_shift(const TraceParams& p)
     if (p.sc.n_sph_pad <= 256 || getenv("RT_HIP_NO_TILES")) return 0;
     uint32_t s = 6;
     for (uint64_t step = p.cell_step; step > 1 && s > 3; step >>= 1) --s;
+    if (const char* e = getenv("RT_HIP_TILE_SHIFT")) {  // tuning knob
+        const int v = atoi(e);
+        if (v >= 1 && v <= 12) s = (uint32_t)v;
+    }
     while ((((uint64_t)p.cell_count + (1ull << s) - 1) >> s) > (1ull << 18)) ++s;
     return s;
 }
