@@ -67,6 +67,12 @@ __device__ __forceinline__ unsigned mbcnt64(unsigned long long m)
 {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
+// 64-bit integer add to a location in LDS (ds_add_u64; wavefront scope is all the callers need).
+__device__ __forceinline__ void lds_add_u64(unsigned long long* p, unsigned long long v)
+{
+    typedef __attribute__((address_space(3))) unsigned long long LdsU64;
+    __hip_atomic_fetch_add((LdsU64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
 // LDS traffic between lanes of one wave: order the DS instructions, nothing leaves the CU.
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -762,10 +768,13 @@ __device__ __forceinline__ Shade shade_hit(const DevScene& sc, F3 o, F3 d, float
 // Per-cell accumulators: fb_q[cell][4] = {sum x, sum y, sum z, segments} as 64-bit integers (32 bytes per cell).
 // flush_cells adds every flushing lane's (x, y, z, segs) to its cell.  Lanes that sit next to each other in the wave and
 // flush into the same cell (the sample blocks of one cell are dealt to neighbouring lanes; the continuing rays they spawn
-// stay neighbours in the ring) are summed in registers first, and the four words of a cell are then added by four
-// neighbouring lanes of ONE wave instruction, so a cell's record travels as a single 32-byte atomic request instead of
-// up to four scattered ones per path.  Wave-uniform control flow; `stage` is >= 576 dwords of the wave's LDS that
-// nothing else uses during the call (the ray stash: dead between the confirm stage and the next step's set-up).
+// stay neighbours in the ring) are summed first, and the four words of a cell are then added by four neighbouring lanes
+// of ONE wave instruction, so a cell's record travels as a single 32-byte atomic request instead of up to four scattered
+// ones per path.  The runs are summed by LDS atomics (ds_add_u64 into one staged record per run: integer adds, so the order
+// does not matter); the register version this replaces -- a six-step segmented reduction over nine shuffled dwords -- cost
+// 1,600 VALU instructions per call, a tenth of a primary step.  Wave-uniform control flow; `stage` is >= 576 dwords of the
+// wave's LDS that nothing else uses during the call (the ray stash and the best keys: dead between the confirm stage and the
+// next step's set-up), 8-byte aligned.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void flush_cells(unsigned long long* fb_q, bool flush, uint32_t cell, unsigned long long x, unsigned long long y,
                                             unsigned long long z, unsigned long long segs, uint32_t* stage, unsigned lane)
@@ -777,38 +786,25 @@ __device__ __forceinline__ void flush_cells(unsigned long long* fb_q, bool flush
     const uint32_t prev = __shfl_up(key, 1, 64);
     const bool head = flush && (lane == 0 || prev != key);
     const unsigned long long hmask = __ballot(head);
-    const uint32_t run = flush ? mbcnt64(hmask) + (head ? 1u : 0u) : 0u;  // heads at or before this lane; 0 = not flushing
-    if (!flush) x = y = z = segs = 0;
-#pragma unroll
-    for (int dlt = 1; dlt < 64; dlt <<= 1) {
-        const uint32_t orun = __shfl_down(run, dlt, 64);
-        const unsigned long long ox = __shfl_down(x, dlt, 64), oy = __shfl_down(y, dlt, 64), oz = __shfl_down(z, dlt, 64),
-                                 os = __shfl_down(segs, dlt, 64);
-        const bool take = flush && lane + dlt < 64 && orun == run;  // runs are contiguous: same run at distance dlt => all between
-        if (take) {
-            x += ox;
-            y += oy;
-            z += oz;
-            segs += os;
-        }
-    }
+    const unsigned n = (unsigned)__builtin_popcountll(hmask);
+    const unsigned e = mbcnt64(hmask) + (head ? 1u : 0u) - 1u;  // this lane's run (flushing lanes only: a head lies at or before them)
     // one staged record per run: {cell} in stage[0..63], {x, y, z, segs} as 8 dwords from stage[64 + 8 e]
-    if (head) {
-        const unsigned e = mbcnt64(hmask);
-        stage[e] = cell;
-        unsigned long long* v = reinterpret_cast<unsigned long long*>(stage + 64 + 8 * e);
-        v[0] = x;
-        v[1] = y;
-        v[2] = z;
-        v[3] = segs;
+    unsigned long long* rec = reinterpret_cast<unsigned long long*>(stage + 64);
+    for (unsigned k = lane; k < 4u * n; k += 64u) rec[k] = 0ull;
+    if (head) stage[e] = cell;
+    wave_lds_sync();
+    if (flush) {
+        lds_add_u64(rec + 4u * e + 0u, x);
+        lds_add_u64(rec + 4u * e + 1u, y);
+        lds_add_u64(rec + 4u * e + 2u, z);
+        lds_add_u64(rec + 4u * e + 3u, segs);
     }
     wave_lds_sync();
-    const unsigned n = (unsigned)__builtin_popcountll(hmask);
     for (unsigned base = 0; base < n; base += 16) {
-        const unsigned e = base + (lane >> 2), c = lane & 3u;
-        if (e < n) {
-            const unsigned long long v = reinterpret_cast<const unsigned long long*>(stage + 64 + 8 * e)[c];
-            if (v) atomicAdd(fb_q + (uint64_t)stage[e] * 4 + c, v);
+        const unsigned r = base + (lane >> 2), c = lane & 3u;
+        if (r < n) {
+            const unsigned long long v = rec[4u * r + c];
+            if (v) atomicAdd(fb_q + (uint64_t)stage[r] * 4 + c, v);
         }
     }
     wave_lds_sync();
@@ -816,7 +812,14 @@ __device__ __forceinline__ void flush_cells(unsigned long long* fb_q, bool flush
 
 // q = rint(v * 2^24); a NaN value (a path the reference's own arithmetic turned into NaN, e.g. a ray that
 // started inside a Box, axis_aligned_box.rs:70-95) contributes 0.
-__device__ __forceinline__ unsigned long long quantize(float v) { return v == v ? (unsigned long long)__float2ll_rn(v * 16777216.0f) : 0ull; }
+__device__ __forceinline__ unsigned long long quantize(float v)
+{
+    const float x = v * 16777216.0f;
+    // path values are sky colours in [0, 1]: the 32-bit conversion (two instructions) serves them; anything else, NaN included,
+    // takes the 64-bit one (a dozen).  Same rounding (to nearest even), same result.
+    if (__builtin_fabsf(x) < 2147483520.0f) return (unsigned long long)(long long)__float2int_rn(x);
+    return v == v ? (unsigned long long)__float2ll_rn(x) : 0ull;
+}
 
 }  // namespace
 }  // namespace rt
