@@ -304,6 +304,24 @@ int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream,
     return RT_OK;
 }
 
+// Samples per work unit of a render call.  The result does not depend on it (integer sums; ids by cell and sample); the speed
+// does.  A unit costs ~900 instructions to deal, cull for and flush, so longer is cheaper; but the 64 lanes of a group should
+// share as few cells as the sample count allows (lanes on one cell start with the same ray, list the same spheres, and their
+// continuing rays walk together), and the units of a cell should be of one length (a group waits for its longest unit).
+// Measured on one GPU, C2 scene / C4 scene, frame time by unit length:
+//   64 spp: 2 3.82, 4 3.43, 8 3.52, 16 4.33, 32 6.04 ms | C4 64 spp: 4 27.4, 8 33.1 ms | C4 256 spp: 8 76.6, 16 93.4 ms
+//   C4 1,024 spp: 8 244, 16 234, 32 281 ms | 16 spp: 2 1.25, 4 1.33 ms | 12 spp: 2 1.10, 3 1.08, 4 1.20, 12 2.18 ms
+// Rule: spp / 64 within [4, 16] (2 up to 16 spp), then the nearest exact divisor of spp up to twice that, if there is one.
+uint32_t render_unit_samples(uint32_t spp)
+{
+    uint32_t target = spp >= 32 ? spp / 64 : (spp > 16 ? 4u : 2u);
+    if (spp >= 32) target = target < 4 ? 4u : (target > 16 ? 16u : target);
+    if (target > spp) target = spp ? spp : 1u;
+    for (uint32_t u = target; u <= 2 * target && u <= 16; ++u)
+        if (spp % u == 0) return u;
+    return target;
+}
+
 // rt_hip_render_dev and rt_hip_render_dev_noalloc: everything after the argument checks (g_mu held, device selected).
 int render_enqueue(const rt_scene* scene, const RtRayGenerator* gen, uint32_t spp, RtSettings settings, uint64_t seed, uint64_t cell_begin,
                    uint64_t cell_count, uint64_t cell_step, float* d_fb, int32_t* d_first_id, float* d_first_t, uint32_t* d_seg_count,
@@ -314,8 +332,12 @@ int render_enqueue(const rt_scene* scene, const RtRayGenerator* gen, uint32_t sp
     p.rays = nullptr;
     p.gen = make_dev_gen(*gen);
     p.spp = spp;
-    p.unit_samples = rt::kUnitSamples;
-    p.units_per_cell = (spp + rt::kUnitSamples - 1) / rt::kUnitSamples;
+    p.unit_samples = p.gen.kind == RT_GEN_PARALLEL_GRID ? rt::kUnitSamples : render_unit_samples(spp);  // the general kernel's lanes are on their own
+    if (const char* e = getenv("RT_HIP_UNIT_SAMPLES")) {  // tuning knob: the result does not depend on it (integer sums, ids by cell and sample)
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4096) p.unit_samples = (uint32_t)v;
+    }
+    p.units_per_cell = (spp + p.unit_samples - 1) / p.unit_samples;
     p.cell_count = (uint32_t)cell_count;
     p.cell_begin = cell_begin;
     p.cell_step = cell_step;

@@ -9,7 +9,7 @@ namespace rt {
 
 constexpr int kTileSpheres = 1024;  // largest sphere table staged in LDS (16 KiB of float4); larger scenes are streamed from L2
 constexpr int kBlockThreads = 256;  // 4 waves
-constexpr uint32_t kUnitSamples = 8;  // samples of one cell traced back to back by one lane (render work unit)
+constexpr uint32_t kUnitSamples = 8;  // samples of one cell traced back to back by one lane: the general kernel's render work unit (the Projector path picks its own, rt_capi.cpp render_unit_samples)
 constexpr int kMaxDevices = 64;     // per-device launch state (function attributes, occupancy) is kept in arrays of this size
 constexpr int kUnroll = 4;          // spheres per scan step; sphere arrays are padded to a multiple
 

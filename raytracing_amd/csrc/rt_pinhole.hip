@@ -251,12 +251,15 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
             for (int r = 0; r < R; ++r) {
                 bool need_unit = (um[r] == 0xffffffffu);
                 unsigned long long need = __ballot(need_unit);
-                if (need && !exhausted) {
+                if (need == ~0ull && !exhausted) {
                     // Units come in batches of 64 from kUnitCounters interleaved work counters (batch b belongs to counter
                     // b % kUnitCounters): all waves of the chip adding to ONE address took, by that counter alone, the time of a
                     // third of a C2 frame.  A wave starts at its own counter and moves on when one runs out, so neighbouring
                     // batches are still in flight at the same time (cull lists, grid cells and accumulators stay cache-warm).
-                    // Lanes a depleted batch cannot serve (ragged units) sit this step out and are served from the next.
+                    // A group takes a new batch only when all of its lanes are through: lanes whose unit was shorter (the last
+                    // sample block of a cell when spp is not a multiple of the unit) wait for the others.  Serving them at once
+                    // let the lanes of a group drift over cells of many batches, and a group whose cells are far apart rebuilds
+                    // an overflowing cull list at every step (spp 64 in units of 6: 24 ms instead of 3.5 ms per C2 frame).
                     if (chunk_next == chunk_end) {
                         for (;;) {
                             unsigned long long v = 0;
