@@ -33,9 +33,6 @@ namespace {
 // ray per lane, RT_PIN_R = 1; 109 with two).  Measured alternatives (two rays per lane): 384 threads / 3 waves per
 // SIMD / 168 VGPRs and 256 threads / 2 waves per SIMD / 187 VGPRs without spills were both slower (C2 frame 9.9 ms and 7.7 ms
 // against 6.0 ms): the grid walk lives on occupancy, not on registers.
-#ifndef RT_X
-#define RT_X 0
-#endif
 #ifndef RT_PRIMARY_REUSE
 #define RT_PRIMARY_REUSE 0
 #endif
@@ -360,7 +357,7 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
             if (any_fresh) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (cull_stale[r] && RT_X != 2) {
+                if (cull_stale[r]) {
                     n_cull[r] = cull_group(p.prim_table, n_pad, p.tile_lists, p.tile_shift, cull_geom(kernarg_gen(offsetof(TraceParams, gen))), c.ci[r], c.cj[r], um[r], live[r],
                                            cull_all[wave][r], lane);
                     cull_stale[r] = false;
@@ -450,7 +447,7 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
         // ---- drain the candidate queue, resolve ----
         RT_T0(6)  // region 6: last confirm batch
         wave_lds_sync();
-        if (tail != head && RT_X != 3) confirm_batch<R>(w, sc, head, tail - head, lane);
+        if (tail != head) confirm_batch<R>(w, sc, head, tail - head, lane);
         wave_lds_sync();
         if (RT_PRIMARY_REUSE && !do_sec) {
 #pragma unroll
@@ -516,7 +513,7 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
                         if (p.first_id) p.first_id[rm[r]] = -1;
                         if (p.first_t) p.first_t[rm[r]] = __builtin_inff();
                     }
-                    if (RT_X != 4) value = sky(rd[r]);
+                    value = sky(rd[r]);
                     ended = true;
                 }
                 if (!do_sec) {
@@ -550,9 +547,7 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
             if (!do_sec) { RT_T1(13) }
             RT_T0(14)
             // per-cell sums: neighbouring lanes of one cell are combined first (rt_device.h flush_cells)
-#if RT_X != 1
             flush_cells(p.fb_q, fl, fcell, fx, fy, fz, fsegs, reinterpret_cast<uint32_t*>(&w.stash[0][0]), lane);
-#endif
             if (!do_sec) { RT_T1(14) }
             RT_T0(15)
             // append continuing rays to the ring (wave-uniform control flow)
