@@ -622,13 +622,41 @@ __device__ __forceinline__ unsigned cull_group(const float4* table, unsigned n_p
                                                uint32_t m, bool live, float4* list, unsigned lane)
 {
     const float inf = __builtin_inff();
-    const float imin = wave_min(live ? ci : inf), imax = wave_max(live ? ci : -inf);
-    const float jmin = wave_min(live ? cj : inf), jmax = wave_max(live ? cj : -inf);
-    if (!(imin <= imax)) return 0;  // no live slot in this group
+    const unsigned long long lmask = __ballot(live);
+    if (!lmask) return 0;  // no live slot in this group
+    float imin, imax, jmin, jmax;
+    unsigned mmin, mmax;
+    // A group takes its units in lane order (lane l of a batch holds unit base + l), so its live lanes are lanes 0 .. n - 1 and
+    // their work items, hence their cells and the column index i, do not decrease with the lane: the extremes sit in the first and
+    // the last live lane.  The row index j wraps where i changes; only then (and for any other lane pattern) the six wave
+    // reductions are needed.  They were a third of the ~900 instructions a batch costs beyond its rays.
+    const unsigned n_live = (unsigned)__builtin_popcountll(lmask);
+    const bool dense = lmask == (n_live == 64u ? ~0ull : ((1ull << n_live) - 1ull));
+    const unsigned last = n_live - 1u;
+    const float i0 = sgpr(ci), i1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ci), last));
+    if (dense && i0 == i1) {
+        imin = imax = i0;
+        jmin = sgpr(cj);
+        jmax = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cj), last));
+        mmin = __builtin_amdgcn_readfirstlane(m);
+        mmax = __builtin_amdgcn_readlane(m, last);
+        if (jmax < jmin) {  // a negative cell stride is not a thing (cell_step is unsigned), but cost nothing to allow
+            const float t = jmin;
+            jmin = jmax;
+            jmax = t;
+        }
+    } else {
+        imin = wave_min(live ? ci : inf);
+        imax = wave_max(live ? ci : -inf);
+        jmin = wave_min(live ? cj : inf);
+        jmax = wave_max(live ? cj : -inf);
+        mmin = wave_min_u32(live ? m : 0xffffffffu);
+        mmax = wave_max_u32(live ? m : 0u);
+    }
     const CullBox x = cull_box(q, imin, imax, jmin, jmax);
     if (tl) {
-        const unsigned t0 = __builtin_amdgcn_readfirstlane(wave_min_u32(live ? m : 0xffffffffu) >> tile_shift);
-        const unsigned t1 = __builtin_amdgcn_readfirstlane(wave_max_u32(live ? m : 0u) >> tile_shift);
+        const unsigned t0 = __builtin_amdgcn_readfirstlane(mmin) >> tile_shift;
+        const unsigned t1 = __builtin_amdgcn_readfirstlane(mmax) >> tile_shift;
         unsigned n = 0;
         if (t1 - t0 <= 1u && cull_tiles(table, tl, t0, t1, x, list, lane, n)) return n;
     }
