@@ -311,10 +311,11 @@ int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream,
 // Measured on one GPU, C2 scene / C4 scene, frame time by unit length:
 //   64 spp: 2 3.82, 4 3.43, 8 3.52, 16 4.33, 32 6.04 ms | C4 64 spp: 4 27.4, 8 33.1 ms | C4 256 spp: 8 76.6, 16 93.4 ms
 //   C4 1,024 spp: 8 244, 16 234, 32 281 ms | 16 spp: 2 1.25, 4 1.33 ms | 12 spp: 2 1.10, 3 1.08, 4 1.20, 12 2.18 ms
-// Rule: spp / 64 within [4, 16] (2 up to 16 spp), then the nearest exact divisor of spp up to twice that, if there is one.
+//   256 spp: 4 10.5, 8 10.1 ms | 128 spp: 2 6.70, 4 5.75, 8 6.01 ms
+// Rule: spp / 32 within [4, 16] (2 up to 16 spp), then the nearest exact divisor of spp up to twice that, if there is one.
 uint32_t render_unit_samples(uint32_t spp)
 {
-    uint32_t target = spp >= 32 ? spp / 64 : (spp > 16 ? 4u : 2u);
+    uint32_t target = spp >= 32 ? spp / 32 : (spp > 16 ? 4u : 2u);
     if (spp >= 32) target = target < 4 ? 4u : (target > 16 ? 16u : target);
     if (target > spp) target = spp ? spp : 1u;
     for (uint32_t u = target; u <= 2 * target && u <= 16; ++u)

@@ -1008,3 +1008,28 @@ def test_cull_tile_lists_change_nothing(engine, n_spheres, spp, w, h, crowd):
         for a, b, c in zip(got[:4], plain[:4], want[:4]):
             assert np.array_equal(a, b) and np.array_equal(a, c)
         assert got[4] == plain[4] == want[4]
+
+
+@pytest.mark.parametrize("spp", [13, 64])
+def test_work_unit_length_changes_nothing(engine, spp):
+    """The host picks the length of a work unit (samples of one cell traced by one lane) by sample count
+    (rt_capi.cpp render_unit_samples); sums are integers and ids go by cell and sample, so any length gives the oracle's frame.
+    RT_HIP_UNIT_SAMPLES overrides the choice: lengths that divide spp, that do not (ragged last blocks: the group waits), 1 and
+    more than spp."""
+    objs = random_scene(300, 1, seed=spp, extent=(30.0, 18.0, 30.0))
+    gen = projector((0.0, 1.0, -70.0), (-32.0, -19.0, -30.0), (64.0, 0.0, 0.0), (0.0, 38.0, 0.0), 60, 44, 1.0)
+    st = SimulationSettingsConfig(40.0, 5)
+    sc = engine.Scene(objs)
+    want = ob.OracleScene(objs).render(gen, spp, 40.0, 5, seed=3, threads=8)
+    for unit in (None, 1, 3, 8, 16, 100):
+        if unit is None:
+            os.environ.pop("RT_HIP_UNIT_SAMPLES", None)
+        else:
+            os.environ["RT_HIP_UNIT_SAMPLES"] = str(unit)
+        try:
+            got = sc.render(gen, spp, st, seed=3)
+        finally:
+            os.environ.pop("RT_HIP_UNIT_SAMPLES", None)
+        for a, b in zip(got[:4], want[:4]):
+            assert np.array_equal(a, b), unit
+        assert got[4] == want[4], unit
