@@ -116,6 +116,16 @@ rt::DevGen make_dev_gen(const RtRayGenerator& g)
     d.dir_n[0] = x * rcp;
     d.dir_n[1] = y * rcp;
     d.dir_n[2] = z * rcp;
+    double m2 = 0.0, ul2 = 0.0, vl2 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        const double m = (std::fabs((double)d.corner[k]) + std::fabs((double)d.a[k])) + ((double)cu * std::fabs((double)d.u_step[k]) + (double)cv * std::fabs((double)d.v_step[k]));
+        m2 += m * m;
+        ul2 += (double)d.u_step[k] * d.u_step[k];
+        vl2 += (double)d.v_step[k] * d.v_step[k];
+    }
+    d.cull_M = (float)(std::sqrt(m2) * 1.001);  // NaN / inf data: the cull then keeps every sphere
+    d.cull_ul = (float)(std::sqrt(ul2) * 1.001);
+    d.cull_vl = (float)(std::sqrt(vl2) * 1.001);
     return d;
 }
 

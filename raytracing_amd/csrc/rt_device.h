@@ -434,7 +434,7 @@ __device__ __forceinline__ float wave_max(float v)
 // largest cell indices of the launch).
 struct CullGeom {
     F3 c0, us, vs;
-    float M;
+    float M, ul, vl;  // M as above; |us|, |vs| (all three rounded up on the host: make_dev_gen)
 };
 __device__ __forceinline__ CullGeom cull_geom(const DevGen& g)
 {
@@ -442,12 +442,9 @@ __device__ __forceinline__ CullGeom cull_geom(const DevGen& g)
     q.c0 = f3(g.corner[0] - g.a[0], g.corner[1] - g.a[1], g.corner[2] - g.a[2]);
     q.us = f3(g.u_step[0], g.u_step[1], g.u_step[2]);
     q.vs = f3(g.v_step[0], g.v_step[1], g.v_step[2]);
-    const float iu = (float)g.count_u, jv = (float)g.count_v;
-    float m[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-        m[k] = (__builtin_fabsf(g.corner[k]) + __builtin_fabsf(g.a[k])) + (iu * __builtin_fabsf(g.u_step[k]) + jv * __builtin_fabsf(g.v_step[k]));
-    q.M = __builtin_sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) * 1.001f;
+    q.M = g.cull_M;
+    q.ul = g.cull_ul;
+    q.vl = g.cull_vl;
     return q;
 }
 // A member of the kernel's argument block (TraceParams is the first argument of every kernel here, so the block starts with
@@ -476,6 +473,9 @@ __device__ __forceinline__ DevGen kernarg_gen(size_t offset)
         g.v_step[k] = gp->v_step[k];
         g.dir_n[k] = gp->dir_n[k];
     }
+    g.cull_M = gp->cull_M;
+    g.cull_ul = gp->cull_ul;
+    g.cull_vl = gp->cull_vl;
     return g;
 }
 __device__ __forceinline__ DevGrid kernarg_grid(size_t offset)
@@ -524,7 +524,7 @@ __device__ __forceinline__ CullBox cull_box(const CullGeom& q, float imin, float
     b.Lc = sgpr(__builtin_sqrtf(dot(vc, vc)));
     b.gu = sgpr(dot(vc, q.us) / b.Lc);  // L_c = 0: NaN, and every sphere is kept
     b.gv = sgpr(dot(vc, q.vs) / b.Lc);
-    const float W = b.di * __builtin_sqrtf(dot(q.us, q.us)) + b.dj * __builtin_sqrtf(dot(q.vs, q.vs));
+    const float W = b.di * q.ul + b.dj * q.vl;
     b.slop0 = sgpr(32.0f * u * q.M + 0x1p-19f * (b.Lc + W) + 8.0f * u * W * (1.0f + q.M / b.Lc));
     return b;
 }
@@ -583,16 +583,15 @@ __device__ __forceinline__ bool cull_tiles(const float4* table, const uint32_t* 
         const uint32_t* rec = tl + (size_t)t * kTileRec;
         const unsigned cnt = __builtin_amdgcn_readfirstlane(rec[0]);
         if (cnt > kTileListCap) return false;
-        const unsigned k0 = lane < cnt ? rec[1u + lane] : 0u, k1 = lane + 64u < cnt ? rec[65u + lane] : 0u;
-        const float4 e0 = table[k0], e1 = table[k1];
-        const bool p0 = lane < cnt && cull_pass(x, e0.x, e0.y, e0.z), p1 = lane + 64u < cnt && cull_pass(x, e1.x, e1.y, e1.z);
-        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
-        const unsigned pos0 = n + mbcnt64(m0);
-        if (p0 && pos0 < kCullCap) list[pos0] = make_float4(e0.x, e0.y, e0.z, __uint_as_float(k0));
-        n += (unsigned)__builtin_popcountll(m0);
-        const unsigned pos1 = n + mbcnt64(m1);
-        if (p1 && pos1 < kCullCap) list[pos1] = make_float4(e1.x, e1.y, e1.z, __uint_as_float(k1));
-        n += (unsigned)__builtin_popcountll(m1);
+        for (unsigned base = 0; base < cnt; base += 64u) {  // one row, two for a long list
+            const unsigned k0 = base + lane < cnt ? rec[1u + base + lane] : 0u;
+            const float4 e0 = table[k0];
+            const bool p0 = base + lane < cnt && cull_pass(x, e0.x, e0.y, e0.z);
+            const unsigned long long m0 = __ballot(p0);
+            const unsigned pos0 = n + mbcnt64(m0);
+            if (p0 && pos0 < kCullCap) list[pos0] = make_float4(e0.x, e0.y, e0.z, __uint_as_float(k0));
+            n += (unsigned)__builtin_popcountll(m0);
+        }
     }
     n_out = n;
     return true;

@@ -100,6 +100,9 @@ struct DevGen {
     uint32_t kind, count_u, count_v;
     float current_ior;
     float a[3], corner[3], u_step[3], v_step[3], dir_n[3];
+    // for the Projector's cull (rt_device.h cull_group), rounded up: |m| with m_k = |corner_k| + |a_k| + count_u |u_step_k| +
+    // count_v |v_step_k| (the largest magnitude the per-ray target - origin arithmetic can meet), |u_step| and |v_step|
+    float cull_M, cull_ul, cull_vl;
 };
 
 struct TraceParams {
