@@ -237,6 +237,7 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
         uint32_t rm[R], rsample[R], rb[R];
         bool live[R], scan_live[R];
         bool fresh[R];  // primary step: this lane's unit is at its first sample, so its ray has not been scanned yet
+        bool have_best = true;  // w.best holds this step's scan results (false: a primary step whose cull lists were empty)
 #pragma unroll
         for (int r = 0; r < R; ++r) fresh[r] = false;
         unsigned head = 0, tail = 0;
@@ -331,19 +332,12 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
                 const float (*ur)[64] = unit_ray_all[wave][r];  // written by this lane when its unit was dealt
                 rd[r] = live[r] ? f3(ur[0][lane], ur[1][lane], ur[2][lane]) : f3(0.f, 0.f, 0.f);
                 rior[r] = p.gen.current_ior;
-                const float a = dot(rd[r], rd[r]);
-                const unsigned slot = r * 64 + lane;
-                w.stash[0][slot] = ro[r].x; w.stash[1][slot] = ro[r].y; w.stash[2][slot] = ro[r].z;
-                w.stash[3][slot] = rd[r].x; w.stash[4][slot] = rd[r].y; w.stash[5][slot] = rd[r].z;
-                w.stash[6][slot] = a;
-                w.best[slot] = kNoHit;
                 // shared-origin filter constants: cell indices (exact in f32) and a lower bound of |target - O|
                 c.ci[r] = live[r] ? ur[3][lane] : 0.0f;
                 c.cj[r] = live[r] ? ur[4][lane] : 0.0f;
                 c.lt[r] = live[r] ? ur[5][lane] : __builtin_inff();  // dead slots are masked by `live`
                 fresh[r] = live[r] && (!RT_PRIMARY_REUSE || usegs[r] == 0u);  // usegs counts the unit's primary segments
             }
-            wave_lds_sync();
             if (true) { RT_T1(2) }
             if (true) { RT_T1(12) }
             RT_T0(4)  // region 4: cull lists and the primary scan over them
@@ -373,15 +367,31 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
 #if RT_DBG_WALK == 9
             if (lane == 0 && !listed) ++my_dbg;
 #endif
-            if (listed) {
+            // A group with empty lists (most of C2's: 0.4 entries on average) has nothing to scan and nothing to confirm: its rays'
+            // stash and best keys are not even written, and the step goes on with "no scan-path hit".
+            bool scan = !listed || RT_PRIMARY_REUSE;
+#pragma unroll
+            for (int r = 0; r < R; ++r) scan |= n_cull[r] != 0u;
+            have_best = scan;
+            if (scan) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const unsigned slot = r * 64 + lane;
+                    w.stash[0][slot] = ro[r].x; w.stash[1][slot] = ro[r].y; w.stash[2][slot] = ro[r].z;
+                    w.stash[3][slot] = rd[r].x; w.stash[4][slot] = rd[r].y; w.stash[5][slot] = rd[r].z;
+                    w.stash[6][slot] = dot(rd[r], rd[r]);
+                    w.best[slot] = kNoHit;
+                }
                 wave_lds_sync();
+                if (listed) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) scan_cull_list<R>(cull_all[wave][r], n_cull[r], r, c.ci[r], c.cj[r], c.lt[r], fresh[r], w, sc, head, tail, lane);
-            } else {
-                // more spheres in reach than a list holds (the origin sits inside a crowd): these rays take the general filter
+                    for (int r = 0; r < R; ++r) scan_cull_list<R>(cull_all[wave][r], n_cull[r], r, c.ci[r], c.cj[r], c.lt[r], fresh[r], w, sc, head, tail, lane);
+                } else {
+                    // more spheres in reach than a list holds (the origin sits inside a crowd): these rays take the general filter
 #pragma unroll
-                for (int r = 0; r < R; ++r) general_consts<R>(c, r, ro[r], rd[r], dot(rd[r], rd[r]), fresh[r], sc);
-                general_scan<R, STREAM>(gm == 1, tileG, n_pad, stage, c, w, sc, head, tail, lane);
+                    for (int r = 0; r < R; ++r) general_consts<R>(c, r, ro[r], rd[r], dot(rd[r], rd[r]), fresh[r], sc);
+                    general_scan<R, STREAM>(gm == 1, tileG, n_pad, stage, c, w, sc, head, tail, lane);
+                }
             }
             }
             RT_T1(4)
@@ -446,9 +456,11 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
         if (do_sec) { RT_T1(5) }
         // ---- drain the candidate queue, resolve ----
         RT_T0(6)  // region 6: last confirm batch
-        wave_lds_sync();
-        if (tail != head) confirm_batch<R>(w, sc, head, tail - head, lane);
-        wave_lds_sync();
+        if (have_best) {
+            wave_lds_sync();
+            if (tail != head) confirm_batch<R>(w, sc, head, tail - head, lane);
+            wave_lds_sync();
+        }
         if (RT_PRIMARY_REUSE && !do_sec) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -478,7 +490,7 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
             if (live[r]) {
                 const unsigned slot = r * 64 + lane;
                 int sj;
-                const unsigned long long kscan = scan_key(sc, w.best[slot], need_obj, sj);
+                const unsigned long long kscan = scan_key(sc, have_best ? w.best[slot] : kNoHit, need_obj, sj);
                 unsigned long long key = planes_min_key(sc, ro[r], rd[r], kscan);
                 PreHit pre;
                 pre.valid = false;
