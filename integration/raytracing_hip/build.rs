@@ -14,11 +14,16 @@ fn main() {
         .arg(&lib)
         .arg(csrc.join("rt_kernels.hip"))
         .arg(csrc.join("rt_pinhole.hip"))
+        .arg(csrc.join("rt_scratch.hip"))
         .arg(csrc.join("rt_capi.cpp"))
         .status()
         .expect("hipcc not found (set HIPCC)");
     assert!(status.success(), "hipcc failed");
-    for f in ["rt_kernels.hip", "rt_pinhole.hip", "rt_capi.cpp", "rt_device.h", "rt_complex.h", "rt_internal.h", "rt_host_shapes.h", "rt_host_bvh.h"] {
+    // every prerequisite of csrc/Makefile's library rule (tests/test_abi.py compares the two lists)
+    for f in [
+        "rt_kernels.hip", "rt_pinhole.hip", "rt_scratch.hip", "rt_capi.cpp", "rt_internal.h", "rt_device.h", "rt_complex.h",
+        "rt_host_shapes.h", "rt_host_bvh.h", "rt_host_grid.h", "rt_grid.h",
+    ] {
         println!("cargo:rerun-if-changed={}", csrc.join(f).display());
     }
     println!("cargo:rustc-link-search=native={}", out.display());

@@ -95,3 +95,35 @@ def test_entry_points_are_callable_from_any_thread():
     t.start()
     t.join()
     assert out["rc"] == abi.RT_ERR_NOT_INIT and b"rt_hip_init" in out["msg"]
+
+
+def _makefile_lists():
+    """(compiled sources, all prerequisites) of the library rule in raytracing_amd/csrc/Makefile."""
+    mk = open(os.path.join(ROOT, "raytracing_amd", "csrc", "Makefile")).read()
+    rule = re.search(r"^\$\(OUT\):(.*)\n\t(.*)$", mk, flags=re.M)
+    prereq = sorted(os.path.basename(f) for f in rule.group(1).split() if not f.endswith("rt_hip.h"))
+    compiled = sorted(f for f in rule.group(2).split() if f.endswith((".hip", ".cpp")))
+    return compiled, prereq
+
+
+def test_rust_binding_builds_the_same_sources_as_the_makefile():
+    """integration/raytracing_hip/build.rs and the excerpt in INTEGRATION.md must compile exactly the translation units the
+    Makefile links into librt_hip.so, and build.rs must watch every prerequisite (round 2 shipped a build.rs without
+    rt_scratch.hip: an unresolved symbol for every Rust caller)."""
+    compiled, prereq = _makefile_lists()
+    assert "rt_scratch.hip" in compiled and len(compiled) >= 4
+    # every file the Makefile names exists, and every source / header in csrc/ is a prerequisite (nothing forgotten there either)
+    csrc = os.path.join(ROOT, "raytracing_amd", "csrc")
+    on_disk = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h")))
+    assert prereq == on_disk
+    rs = open(os.path.join(ROOT, "integration", "raytracing_hip", "build.rs")).read()
+    hipcc_call = rs[rs.index("Command::new"):rs.index(".status()")]
+    assert sorted(re.findall(r'csrc\.join\("([\w.]+)"\)', hipcc_call)) == compiled
+    watched = re.search(r"for f in \[(.*?)\]", rs, flags=re.S).group(1)
+    assert sorted(re.findall(r'"([\w.]+)"', watched)) == prereq
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    excerpt = md[md.index("crates/raytracing_hip/build.rs"):md.index("crates/raytracing_hip/src/lib.rs")]
+    comment = [ln for ln in excerpt.splitlines() if "librt_hip.so" in ln and ln.strip().startswith("//")][0]
+    assert sorted(os.path.basename(f) for f in re.findall(r"csrc/([\w.]+)", comment)) == compiled
+    args = re.search(r'\.args\(\[("csrc/.*?)\]\)', excerpt).group(1)
+    assert sorted(os.path.basename(f) for f in re.findall(r'"csrc/([\w.]+)"', args)) == compiled
