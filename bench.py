@@ -1,17 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s of the ray-path hot loop (BASELINE.json metric).
 
-A step = one pass of the hot path over one frame of synthetic input.  A "ray" = one bounce-loop iteration
-(scene.rs:49), counted by the kernel.
+A step = one pass of the hot path over one frame (or one batch of explicit rays) of synthetic input.  A "ray" = one
+bounce-loop iteration (scene.rs:49), counted by the kernel.
 
   --gpus 1 (default)  workload C2 = BASELINE.json configs[1], the configuration the metric is quoted on: 1,000 spheres,
                       Projector 1920x1080 cells, 64 paths per cell, max_bounces 8, one launch per frame.
+                      The line also carries `config.secondary`: the reference's own call shape (explicit rays in,
+                      polylines out, rt_hip_simulate_dev) on the same scene.
   --gpus N > 1        (launched by torch.distributed.run, one rank per GPU) workload C4 = configs[3]: 10,000 spheres,
                       3840x2160 cells, 1,024 spp, the frame's cells dealt round-robin over the ranks
                       (sharding.cell_shard), ONE all_gather_into_tensor over RCCL per frame inside the timed region, fixed
                       total work ("scaling": "strong").  Rank 0 checks the gathered image against the stored single-GPU
                       checksum (tests/golden/frame_checksums.json) after the timed region.
-  --workload c2|c4    overrides the choice (e.g. `--gpus 1 --workload c4` = the single-GPU reference of the scaling curve).
+  --workload c2|c3|c4|simulate   overrides the choice: `c4` on one GPU = the single-GPU point of the scaling curve; `c3` =
+                      configs[2] (100k-triangle mesh, BVH path, 256 spp); `simulate` = Scene::simulate_rays' call shape
+                      (scene.rs:39): 4,147,200 explicit rays on the C2 scene, polylines written to HBM.
+
+roofline: EXECUTED work.  The numerator is the wave-level VALU instruction count of this workload's
+frame, by instruction class, from the committed rocprofv3 PMC pass (profiles/pmc_constants.json); it is used only if that
+pass was taken from the very sources this library was built from (SHA-256 over raytracing_amd/csrc, tools/csrc_hash.py)
+and for this width / height / spp / depth — otherwise every PMC-derived field is null and `pmc_stale` says why.  The
+ceiling weights that instruction mix with the issue cost of each class measured on this chip
+(profiles/valu_class_cycles.json, tools/ubench/valu_rate.hip).
 
 Prints ONE JSON line on rank 0.
 """
@@ -23,13 +34,21 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 FLOP_PER_TEST = 17  # algorithmic reject-path cost of one ray-sphere test (sphere.rs:13-17)
-PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (packed FMA) at 2.4 GHz
-# VALU issue peak: 256 CUs x 4 SIMDs, one wave-level VALU instruction per 4 cycles per SIMD, 2.4 GHz (MI355X_MICROARCH.md)
-PEAK_VALU_GINST = 256 * 4 * 2.4 / 4.0
+PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (v_fma_f32 every 2 cycles per SIMD: 256 FLOP/clk/CU) at 2.4 GHz
+N_SIMD = 256 * 4
+CLOCK_GHZ = 2.4
+PEAK_VALU_GINST_FP32_RATE = N_SIMD * CLOCK_GHZ / 2.0  # 1,228.8: every instruction at the FMA rate (one per 2 cycles per SIMD)
+PEAK_VALU_GINST_4CYCLE = N_SIMD * CLOCK_GHZ / 4.0     # 614.4: rounds 1-2 priced against this (one per 4 cycles)
 CHECKSUMS = os.path.join(ROOT, "tests", "golden", "frame_checksums.json")
 PMC = os.path.join(ROOT, "profiles", "pmc_constants.json")
+RATES = os.path.join(ROOT, "profiles", "valu_class_cycles.json")
+CLASSES = ("FMA_F32", "ADD_F32", "MUL_F32", "TRANS_F32", "INT32", "INT64", "CVT", "OTHER")
+COHERENCE_NOTE = ("the reference's Projector has no jitter (scene_config.rs:84-108), so a cell's samples start as identical primary "
+                  "rays and diverge only at HalfMirrors; every sample's ray is traced (nothing is reused), but cull lists and grid "
+                  "walks ride that coherence -- a jittered tracer would not see this rate")
 
 
 def cpu_baseline(n_spheres):
@@ -62,16 +81,157 @@ def checksum_key(name, w, h, spp, seed, depth):
     return f"{name}:{w}x{h}:spp{spp}:seed{seed}:depth{depth}"
 
 
+def load_json(path):
+    try:
+        return json.load(open(path))
+    except Exception:
+        return {}
+
+
+def pmc_entry(name, run_cfg):
+    """(entry, None) if profiles/pmc_constants.json[name] was collected from these sources and this configuration, else ({}, reason)."""
+    from csrc_hash import csrc_hash
+
+    e = load_json(PMC).get(name)
+    if not e:
+        return {}, f"no entry '{name}' in profiles/pmc_constants.json"
+    have = csrc_hash()
+    if e.get("csrc_sha256") != have:
+        return {}, f"profiles/pmc_constants.json[{name}] was collected from sources {str(e.get('csrc_sha256'))[:12]}, this tree is {have[:12]}: re-run tools/profile_bench.sh"
+    if e.get("config") != run_cfg:
+        return {}, f"profiles/pmc_constants.json[{name}] was collected for {e.get('config')}, this run is {run_cfg}"
+    return e, None
+
+
+def valu_roofline(pmc, stale, rates, render_ms, launches, share, segs_local, kernel_label):
+    """The executed-work roofline of one workload.  render_ms: HIP-event time of one step's launches."""
+    sec = render_ms * 1e-3
+    insts = None if stale else pmc.get("valu_insts_per_frame")
+    mix = None if stale else pmc.get("valu_class_per_frame")
+    achieved = None if insts is None else insts * share / sec / 1e9
+    ceiling = mean_cycles = None
+    if mix and rates:
+        total = sum(mix.get(c, 0.0) for c in CLASSES)
+        if total > 0 and all(c in rates for c in CLASSES):
+            mean_cycles = sum(mix.get(c, 0.0) * rates[c] for c in CLASSES) / total
+            ceiling = N_SIMD * CLOCK_GHZ / mean_cycles
+    traffic = None if stale else pmc.get("hbm_bytes_per_frame")
+    clk = None if stale else pmc.get("clock_ghz")
+    issue, lane = (None, None) if stale else (pmc.get("valu_issue_util"), pmc.get("valu_lane_util"))
+    flops = None if stale else pmc.get("flops_fp32_per_frame")
+    roof = {
+        "bound": "valu_issue",
+        "kernel": kernel_label,
+        "achieved": achieved,
+        "peak": ceiling,
+        "unit": "Ginst/s",
+        "frac": None if achieved is None or ceiling is None else achieved / ceiling,
+        "traffic": None if traffic is None else traffic * share / launches,
+        "kernel_ms": render_ms / launches,
+        "launches_per_step": launches,
+        "definition": "EXECUTED work: wave-level VALU instructions of this rank's share of the frame (SQ_INSTS_VALU of the committed "
+                      "rocprofv3 pass of this kernel, workload and source hash, profiles/pmc_constants.json) / its kernel time (HIP "
+                      "events on the launch stream).  peak = 1,024 SIMDs x 2.4 GHz / (mean issue cycles of the measured instruction mix: "
+                      "SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F32, _INT32, _INT64, _CVT, rest = OTHER, each weighted with the cycles per "
+                      "wave instruction measured on this chip by tools/ubench/valu_rate.hip, profiles/valu_class_cycles.json).  "
+                      "frac_fp32_rate prices every instruction at the FP32 FMA rate (2 cycles, MI355X_MICROARCH.md: 1,228.8 Ginst/s), "
+                      "frac_4cycle at the 4-cycle rate rounds 1-2 used (614.4).",
+        "mean_issue_cycles_of_mix": mean_cycles,
+        "frac_fp32_rate": None if achieved is None else achieved / PEAK_VALU_GINST_FP32_RATE,
+        "frac_4cycle": None if achieved is None else achieved / PEAK_VALU_GINST_4CYCLE,
+        "valu_class_mix": None if not mix else {c: mix.get(c, 0.0) / max(1.0, sum(mix.get(k, 0.0) for k in CLASSES)) for c in CLASSES},
+        "valu_class_cycles": rates or None,
+        "valu_insts_per_segment": None if insts is None or not segs_local else insts * share / segs_local,
+        "executed_fp32": None if flops is None else {"achieved": flops * share / sec / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                                     "frac": flops * share / sec / 1e12 / PEAK_FP32_TFLOPS,
+                                                     "note": "SQ_INSTS_VALU_FLOPS_FP32 of the same pass: FP32 operations the kernel "
+                                                             "really executed, over the packed-FMA vector peak (north_star's 50 % bar)"},
+        "frac_at_sustained_clock": None if not clk or achieved is None or ceiling is None else achieved / (ceiling * clk / CLOCK_GHZ),
+        "sustained_clock_ghz": clk,
+        "valu_issue_util": issue,
+        "valu_lane_util": lane,
+        "useful_lane_fraction": None if issue is None or lane is None else issue * lane,
+        "pmc_source": None if stale else pmc.get("source"),
+        "pmc_stale": stale,
+        "hbm": None if traffic is None else {"achieved": traffic * share / sec / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                              "frac": traffic * share / sec / 1e9 / 8000.0},
+    }
+    return roof
+
+
+def c2_primary_rays(cfg, copies):
+    """The C2 projector's primary rays as explicit RtRays (scene_config.rs:84-108, vectorised in f32 on the host), `copies` times."""
+    import numpy as np
+
+    from raytracing_amd import abi
+
+    g = cfg["gen"]
+    i, j = np.meshgrid(np.arange(g.count_u, dtype=np.float32), np.arange(g.count_v, dtype=np.float32), indexing="ij")
+    a, corner = np.array(g.a[:], np.float32), np.array(g.corner[:], np.float32)
+    us, vs = (np.array(g.u[:], np.float32) / np.float32(g.count_u)), (np.array(g.v[:], np.float32) / np.float32(g.count_v))
+    target = (corner + i[..., None] * us).astype(np.float32) + j[..., None] * vs
+    d = (target - a).astype(np.float32).reshape(-1, 3)
+    d /= np.sqrt((d * d).sum(1, keepdims=True)).astype(np.float32)
+    rays = np.zeros(len(d) * copies, abi.RAY_DTYPE)
+    rays["origin"] = a
+    rays["direction"] = np.tile(d, (copies, 1))
+    rays["current_ior"] = 1.0
+    return rays
+
+
+class SimulateJob:
+    """rt_hip_simulate_dev over this rank's contiguous share of the explicit rays; everything resident in HBM."""
+
+    def __init__(self, scene, cfg, st, dev, rank, world, copies=2):
+        import numpy as np
+        import torch
+
+        rays = c2_primary_rays(cfg, copies)
+        self.n_total = len(rays)
+        lo, hi = self.n_total * rank // world, self.n_total * (rank + 1) // world
+        self.n, self.base = hi - lo, lo
+        self.scene, self.st, self.seed = scene, st, cfg["seed"]
+        self.d_rays = torch.from_numpy(rays[lo:hi].view(np.uint8).reshape(self.n, -1).copy()).to(dev)
+        self.d_pts = torch.empty((self.n, st.max_bounces + 1, 3), dtype=torch.float32, device=dev)
+        self.d_np = torch.empty(self.n, dtype=torch.int32, device=dev)
+        self.d_tot = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def call(self):
+        self.scene.simulate_rays_dev(self.st, self.d_rays.data_ptr(), self.n, self.seed, self.base, self.d_pts.data_ptr(), self.d_np.data_ptr(), 0,
+                                     self.d_tot.data_ptr(), self.stream)
+
+    def segments(self):
+        return int(self.d_tot.item())
+
+    def algorithmic_bytes(self):
+        """28 B per ray in; per path its polyline (12 B per vertex) and vertex count (4 B) out."""
+        return self.n * 28 + int(self.d_np.sum().item()) * 12 + self.n * 4
+
+
+def time_calls(torch, fn, steps, barrier):
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record()
+        fn(k)
+        ev[k][1].record()
+    barrier()
+    return time.perf_counter() - t0, ev
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["auto", "c2", "c4"], default="auto")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["auto", "c2", "c3", "c4", "simulate"], default="auto")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--print-checksum", action="store_true", help="also print the frame checksum key and value (to store it)")
     args = ap.parse_args()
 
@@ -106,12 +266,13 @@ def main():
     engine.init(dev.index)
 
     name = args.workload if args.workload != "auto" else ("c2" if world == 1 else "c4")
-    make = synth.config_c2 if name == "c2" else synth.config_c4
-    w = args.width or (1920 if name == "c2" else 3840)
-    h = args.height or (1080 if name == "c2" else 2160)
+    scene_name = "c2" if name == "simulate" else name
+    make = {"c2": synth.config_c2, "c3": synth.config_c3, "c4": synth.config_c4}[scene_name]
+    w = args.width or (3840 if scene_name == "c4" else 1920)
+    h = args.height or (2160 if scene_name == "c4" else 1080)
     cfg = make(w, h)
     spp = args.spp or cfg["spp"]
-    scene = engine.Scene(cfg["objects"])
+    scene = engine.Scene(cfg["objects"], meshes=cfg.get("meshes"))
     n_obj, n_sph, n_pl = scene.counts()
     st = SimulationSettingsConfig(cfg["infinity_distance"], cfg["max_bounces"])
     n_cells = w * h
@@ -127,34 +288,47 @@ def main():
         scene.render_dev(cfg["gen"], spp, st, cfg["seed"], begin, count, step, fb_rows.data_ptr(), 0, 0, 0, total_slot.data_ptr(),
                          torch.cuda.current_stream().cuda_stream)
 
-    # inputs (scene, generator constants) and outputs resident in HBM before the timed region; C2's 2,073,600 cells are one launch
-    frame = sharding.ShardedFrame(render_cells, n_cells, rank, world, GlooDist if rehearsal else dist, dev, max_cells_per_launch=1 << 21)
-
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # bring the GPU to its steady clocks before anything is counted (a cold first frame runs ~8 % slower); untimed, like the W
-    # warmup steps (render only, no collective: the number of pre-warm frames is time-based and may differ between ranks)
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.5:
-        frame.render()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        frame.step()
-    barrier()
-    # kernel duration: HIP events on the launch stream around each frame's launches (the collective is outside the pair)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        frame.render()
-        ev[k][1].record()
-        frame.gather()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    segs_local = frame.segments()
+    def prewarm(fn):
+        # bring the GPU to its steady clocks before anything is counted (a cold first frame runs ~8 % slower); untimed, like the W
+        # warmup steps (no collective: the number of pre-warm frames is time-based and may differ between ranks)
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 0.5:
+            fn()
+            torch.cuda.synchronize()
+
+    sim = None
+    if name == "simulate":
+        sim = SimulateJob(scene, cfg, st, dev, rank, world)
+        prewarm(sim.call)
+        for _ in range(args.warmup):
+            sim.call()
+        elapsed, ev = time_calls(torch, lambda k: sim.call(), args.steps, barrier)
+        segs_local = sim.segments()
+        launches, share = 1, sim.n / sim.n_total
+    else:
+        # inputs (scene, generator constants) and outputs resident in HBM before the timed region; C2's 2,073,600 cells are one launch
+        frame = sharding.ShardedFrame(render_cells, n_cells, rank, world, GlooDist if rehearsal else dist, dev, max_cells_per_launch=1 << 21)
+        prewarm(frame.render)
+        for _ in range(args.warmup):
+            frame.step()
+        barrier()
+        # kernel duration: HIP events on the launch stream around each frame's launches (the collective is outside the pair)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            ev[k][0].record()
+            frame.render()
+            ev[k][1].record()
+            frame.gather()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        segs_local = frame.segments()
+        launches, share = len(frame.launches), frame.count / n_cells
     render_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -170,62 +344,53 @@ def main():
     elapsed_max, segs_all = float(t.item()), int(s.item())
 
     if rank == 0:
-        # the assembled image against the stored single-GPU checksum (integer checksum: independent of the rank count)
-        key = checksum_key(name, w, h, spp, cfg["seed"], cfg["max_bounces"])
-        got = sharding.frame_checksum(frame.image())
-        stored = json.load(open(CHECKSUMS)) if os.path.exists(CHECKSUMS) else {}
-        if key in stored:
-            if int(stored[key], 16) != got:
-                raise SystemExit(f"bench.py: frame checksum {got:#018x} differs from the stored single-GPU value {stored[key]} for {key}")
-            image_check = f"gathered image == stored single-GPU checksum {stored[key]}"
+        if sim is None:
+            # the assembled image against the stored single-GPU checksum (integer checksum: independent of the rank count)
+            key = checksum_key(name, w, h, spp, cfg["seed"], cfg["max_bounces"])
+            got = sharding.frame_checksum(frame.image())
+            stored = load_json(CHECKSUMS)
+            if key in stored:
+                if int(stored[key], 16) != got:
+                    raise SystemExit(f"bench.py: frame checksum {got:#018x} differs from the stored single-GPU value {stored[key]} for {key}")
+                image_check = f"gathered image == stored single-GPU checksum {stored[key]}"
+            else:
+                image_check = f"no stored checksum for {key} (computed {got:#018x})"
+            if args.print_checksum:
+                print(f"checksum {key} {got:#018x}", file=sys.stderr, flush=True)
         else:
-            image_check = f"no stored checksum for {key} (computed {got:#018x})"
-        if args.print_checksum:
-            print(f"checksum {key} {got:#018x}", file=sys.stderr, flush=True)
+            image_check = "polylines: bit-exact against the oracle in tests/test_gpu_parity.py (test_simulate_*), not re-checked here"
 
         value = segs_all * args.steps / elapsed_max / 1e6
-        launches = len(frame.launches)
-        kernel_ms = render_ms / launches  # average duration of one launch of the dominant kernel (+ the table, tile-list and finalize kernels and memsets beside it: 2 % on C2, 0.4 % on C4)
-        algorithmic = segs_local * FLOP_PER_TEST * n_sph / (render_ms * 1e-3) / 1e12
-        pmc = {}
-        if os.path.exists(PMC):
-            try:
-                pmc = json.load(open(PMC)).get(name, {})
-            except Exception:
-                pmc = {}
-        traffic = pmc.get("hbm_bytes_per_frame")
-        clk = pmc.get("clock_ghz")
-        share = frame.count / n_cells  # this rank's part of the frame (cells are dealt round-robin: a uniform sample of the image)
-        insts = pmc.get("valu_insts_per_frame")
-        achieved = None if insts is None else insts * share / (render_ms * 1e-3) / 1e9
-        roof = {
-            "bound": "valu_issue",
-            "kernel": "pinhole_kernel<1, %s, false> (Projector render loop, one ray per lane)" % ("false" if n_sph <= 1024 else "true"),
-            "achieved": achieved,
-            "peak": PEAK_VALU_GINST,
-            "unit": "Ginst/s",
-            "frac": None if achieved is None else achieved / PEAK_VALU_GINST,
-            "traffic": None if traffic is None else traffic * share / launches,
-            "kernel_ms": kernel_ms,
-            "launches_per_step": launches,
-            "definition": "EXECUTED work: wave-level VALU instructions of this rank's share of the frame (SQ_INSTS_VALU of the committed "
-                          "rocprofv3 pass of this kernel and workload, profiles/pmc_constants.json) / its kernel time (HIP events on the "
-                          "launch stream), over the VALU issue peak of the chip: 1,024 SIMDs x one wave instruction per 4 cycles at 2.4 GHz. "
-                          "The kernel no longer scans the sphere table: primary rays test a per-wave cull list, continuing rays walk a "
-                          "uniform grid, so FLOP per sphere test is not the executed work any more (algorithmic_equiv keeps that figure).",
-            "frac_at_sustained_clock": None if not clk or achieved is None else achieved / (PEAK_VALU_GINST * clk / 2.4),
-            "sustained_clock_ghz": clk,
-            "valu_issue_util": pmc.get("valu_issue_util"),
-            "valu_lane_util": pmc.get("valu_lane_util"),
-            "pmc_source": pmc.get("source"),
-            "algorithmic_equiv": {"flop_per_test": FLOP_PER_TEST, "achieved": algorithmic, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": algorithmic / PEAK_FP32_TFLOPS,
-                                  "note": "SURVEY.md §8d accounting: 17 FLOP for every (segment, sphere) pair the reference's linear scan would "
-                                          "test, over the FP32 vector peak; far above 1 because almost none of those tests is executed"},
-            "hbm": None if traffic is None else {"achieved": traffic * share / (render_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                                  "frac": traffic * share / (render_ms * 1e-3) / 1e9 / 8000.0},
-        }
-        full = "C2" if name == "c2" else "C4"
+        run_cfg = {"width": w, "height": h, "spp": spp, "max_bounces": cfg["max_bounces"]} if sim is None else \
+                  {"rays": sim.n_total, "max_bounces": cfg["max_bounces"]}
+        pmc, stale = pmc_entry(name, run_cfg)
+        rates = load_json(RATES).get("cycles")
+        if sim is None:
+            kernel = ("pinhole_kernel<1, %s, %s> (Projector render loop, one ray per lane)" % ("false" if n_sph <= 1024 else "true", "true" if name == "c3" else "false"))
+        else:
+            kernel = "trace_kernel (explicit rays, polylines out: the call shape of scene.rs:39)"
+        roof = valu_roofline(pmc, stale, rates, render_ms, launches, share, segs_local, kernel)
+        if sim is None and name != "c3":
+            algorithmic = segs_local * FLOP_PER_TEST * n_sph / (render_ms * 1e-3) / 1e12
+            roof["algorithmic_equiv"] = {"flop_per_test": FLOP_PER_TEST, "achieved": algorithmic, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": algorithmic / PEAK_FP32_TFLOPS,
+                                         "note": "SURVEY.md §8d accounting: 17 FLOP for every (segment, sphere) pair the reference's linear scan "
+                                                 "would test, over the FP32 vector peak; far above 1 because almost none of those tests is "
+                                                 "executed (cull lists + uniform grid, results bit-identical to the linear scan) -- a statement "
+                                                 "about the algorithm, not a roofline"}
+        if sim is not None:
+            ab = sim.algorithmic_bytes()
+            roof["hbm_algorithmic"] = {"bytes_per_call": ab, "achieved": ab / (render_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                       "frac": ab / (render_ms * 1e-3) / 1e9 / 8000.0,
+                                       "note": "28 B per ray in, 12 B per polyline vertex + 4 B per path out (SURVEY §8d)"}
+        full = {"c2": "C2", "c3": "C3", "c4": "C4", "simulate": "simulate_rays on the C2 scene"}[name]
+        if sim is None:
+            workload = (f"{full}: {n_sph} spheres" + (f" + {len(cfg['meshes'][0][1])}-triangle mesh" if name == "c3" else "") +
+                        f" (seed 0xC0FFEE), Projector {w}x{h} cells, {spp} spp, max_bounces {cfg['max_bounces']}; one frame per step" +
+                        ("" if world == 1 else f", cells dealt round-robin over {world} GPUs, one all-gather per frame") + "; " + COHERENCE_NOTE)
+        else:
+            workload = (f"{full}: {n_sph} spheres, {sim.n_total} explicit rays (two copies of the 1920x1080 Projector's primary rays), "
+                        f"max_bounces {cfg['max_bounces']}, polylines [n][{cfg['max_bounces'] + 1}][3] f32 + vertex counts written to HBM; one call per step")
         out = {
             "metric": "Mrays/sec (primary+bounce) at 1080p 64spp, 1/8 GPU; % of FP32 VALU peak",
             "value": value,
@@ -240,18 +405,40 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{full}: {n_sph} spheres (seed 0xC0FFEE), Projector {w}x{h} cells, {spp} spp, max_bounces {cfg['max_bounces']}; "
-                            f"one frame per step" + ("" if world == 1 else f", cells dealt round-robin over {world} GPUs, one all-gather per frame"),
+                "workload": workload,
+                **run_cfg,
                 "segments_per_step": segs_all,
-                "sharding": "single GPU" if world == 1 else "cell = rank + m * world (sharding.cell_shard); framebuffer shards all-gathered over RCCL inside the timed region",
+                "sharding": "single GPU" if world == 1 else ("cell = rank + m * world (sharding.cell_shard); framebuffer shards all-gathered over RCCL inside the timed region"
+                                                             if sim is None else "contiguous ray ranges, no exchange"),
                 "image_check": image_check,
                 # "1/8 GPU" read both ways: value is per whole MI355X (one of a node's eight) at N=1; one XCD's share is value/8/N
                 "mrays_per_s_per_gpu": value / world,
                 "mrays_per_s_per_xcd": value / world / 8,
-                "pct_of_fp32_valu_peak": None if achieved is None else 100.0 * achieved / PEAK_VALU_GINST,
+                # north_star's second number, two honest readings: FP32 operations really executed over the packed-FMA peak, and
+                # VALU instruction issue against the FMA issue rate
+                "pct_of_fp32_valu_peak": None if not roof.get("executed_fp32") else 100.0 * roof["executed_fp32"]["frac"],
+                "pct_of_valu_issue_at_fp32_rate": None if roof["frac_fp32_rate"] is None else 100.0 * roof["frac_fp32_rate"],
             },
             "roofline": roof,
         }
+        if world == 1 and name == "c2" and not args.no_secondary:
+            # the reference's own call shape on the same scene, measured after the headline's timed region
+            sj = SimulateJob(scene, cfg, st, dev, 0, 1)
+            for _ in range(3):
+                sj.call()
+            n_calls = 10
+            el, sev = time_calls(torch, lambda k: sj.call(), n_calls, barrier)
+            sms = sum(a.elapsed_time(b) for a, b in sev) / n_calls
+            ssegs = sj.segments()
+            spmc, sstale = pmc_entry("simulate", {"rays": sj.n_total, "max_bounces": cfg["max_bounces"]})
+            sroof = valu_roofline(spmc, sstale, rates, sms, 1, 1.0, ssegs, "trace_kernel (explicit rays, polylines out)")
+            out["config"]["secondary"] = {
+                "workload": f"Scene::simulate_rays call shape (scene.rs:39, rt_hip_simulate_dev): {sj.n_total} explicit rays on the same scene, polylines out",
+                "value": ssegs * n_calls / el / 1e6, "unit": "Mrays/s", "ms_per_call": el / n_calls * 1e3, "kernel_ms": sms,
+                "segments_per_call": ssegs, "paths_per_s": sj.n_total * n_calls / el,
+                "hbm_algorithmic_gbps": sj.algorithmic_bytes() / (sms * 1e-3) / 1e9,
+                "roofline_frac": sroof["frac"], "roofline_frac_fp32_rate": sroof["frac_fp32_rate"], "pmc_stale": sstale,
+            }
         if world == 1 and name == "c2" and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n_sph)
         print(json.dumps(out), flush=True)

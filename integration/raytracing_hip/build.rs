@@ -10,7 +10,7 @@ fn main() {
     let hipcc = env::var("HIPCC").unwrap_or_else(|_| "/opt/rocm/bin/hipcc".to_string());
     let lib = out.join("librt_hip.so");
     let status = Command::new(&hipcc)
-        .args(["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-shared", "-o"])
+        .args(["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-shared", "-o"])
         .arg(&lib)
         .arg(csrc.join("rt_kernels.hip"))
         .arg(csrc.join("rt_pinhole.hip"))

@@ -102,9 +102,17 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
         // Every lane reads (the indices are clamped, so the address is valid whatever the lane holds) and inactive lanes drop the
         // result: with the load under `if (active)` this compiler (ROCm 7.2 clang, -O1 and -O3 alike) produced a kernel that lost
         // hits on half of the fuzz cases; the two forms mean the same.
+#ifdef RT_GRID_ACTIVE_LOAD  // the form that lost hits (kept for the ISA comparison)
+        if (active) {
+            const unsigned rec = cells[((unsigned)cz * (unsigned)dimy + (unsigned)cy) * (unsigned)dimx + (unsigned)cx];
+            start = rec & 0xfffffu;
+            cnt = rec >> 20;
+        }
+#else
         const unsigned rec = cells[((unsigned)cz * (unsigned)dimy + (unsigned)cy) * (unsigned)dimx + (unsigned)cx];
         start = active ? rec & 0xfffffu : 0u;
         cnt = active ? rec >> 20 : 0u;
+#endif
     }
 #if RT_DBG_WALK == 4
     if (lane == 0) ++dbg;

@@ -179,6 +179,14 @@ inline const toml_lite::Array& list_or_empty(const Value& scene, const std::stri
     return it->second->arr;
 }
 
+// A generator expands on the host (the reference pushes every object / ray into a Vec, scene_config.rs:25-110); a count
+// product beyond this is refused with an error instead of exhausting memory (the reference would abort in the allocator).
+constexpr uint64_t kMaxGeneratorItems = 1ull << 27;
+inline void check_expansion(uint32_t a, uint32_t b, const std::string& where)
+{
+    if ((uint64_t)a * b > kMaxGeneratorItems) throw ConfigError(where + ": generator expands to more than 2^27 items");
+}
+
 inline SimulationConfig from_toml(const std::string& text)
 {
     std::shared_ptr<Value> doc = toml_lite::parse(text);
@@ -201,6 +209,7 @@ inline SimulationConfig from_toml(const std::string& text)
         vec3(req(*e, "step_z", where), where + ".step_z", sz);
         const uint32_t cx = u32(req(*e, "count_x", where), where + ".count_x"), cz = u32(req(*e, "count_z", where), where + ".count_z");
         const Value& tmpl = req(*e, "template", where);
+        check_expansion(cx, cz, where);
         for (uint32_t i = 0; i < cx; ++i)
             for (uint32_t j = 0; j < cz; ++j) {
                 float pos[3];
@@ -226,6 +235,7 @@ inline SimulationConfig from_toml(const std::string& text)
         const std::string ty = str(req(*e, "type", where), where + ".type");
         const uint32_t cu = u32(req(*e, "count_u", where), where + ".count_u"), cv = u32(req(*e, "count_v", where), where + ".count_v");
         const float ior = num(req(*e, "current_ior", where), where + ".current_ior");
+        check_expansion(cu, cv, where);
         float a[3], u[3], v[3], us[3], vs[3];
         if (ty == "ParallelGrid") {  // scene_config.rs:60-83
             float dir[3];

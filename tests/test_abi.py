@@ -127,3 +127,8 @@ def test_rust_binding_builds_the_same_sources_as_the_makefile():
     assert sorted(os.path.basename(f) for f in re.findall(r"csrc/([\w.]+)", comment)) == compiled
     args = re.search(r'\.args\(\[("csrc/.*?)\]\)', excerpt).group(1)
     assert sorted(os.path.basename(f) for f in re.findall(r'"csrc/([\w.]+)"', args)) == compiled
+    # the flags that decide results and speed are the Makefile's too
+    mk = open(os.path.join(ROOT, "raytracing_amd", "csrc", "Makefile")).read()
+    for flag in ("-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-packed-fp32-ops"):
+        assert flag in mk and flag in hipcc_call and flag in excerpt, flag
+    assert "--offload-arch=gfx950" in hipcc_call and "--offload-arch=gfx950" in excerpt

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CK(x)                                                                      \
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed, float
     float2v p4 = p0 + 1.f, p5 = p1 + 1.f, p6 = p2 + 1.f, p7 = p3 + 1.f;
     float2v pa = {a, a}, pb = {b, b};
     unsigned long long acc = 0;
+    if (MODE == 29 || MODE == 38) asm volatile("s_mov_b64 vcc, 0x55555555" ::: "vcc");
     for (int i = 0; i < ITERS; ++i) {
         if (MODE == 0) {
             asm volatile(
@@ -159,6 +161,102 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed, float
                 "v_and_b32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_and_b32 %6, %6, %8\n v_and_b32 %7, %7, %8\n"
                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
                 : "v"(b), "v"(a));
+        }
+
+        else if (MODE == 24) {  // transcendental: v_rcp_f32
+            asm volatile(
+                "v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+                "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+        } else if (MODE == 25) {  // transcendental: v_sqrt_f32 / v_rsq_f32
+            asm volatile(
+                "v_sqrt_f32 %0, %0\n v_rsq_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_rsq_f32 %3, %3\n"
+                "v_sqrt_f32 %4, %4\n v_rsq_f32 %5, %5\n v_sqrt_f32 %6, %6\n v_rsq_f32 %7, %7\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+        } else if (MODE == 26) {  // INT32: v_add_u32 / v_lshlrev_b32 / v_and_b32
+            asm volatile(
+                "v_add_u32 %0, %0, %8\n v_lshlrev_b32 %1, 1, %1\n v_add_u32 %2, %2, %8\n v_and_b32 %3, %3, %8\n"
+                "v_add_u32 %4, %4, %8\n v_lshlrev_b32 %5, 1, %5\n v_add_u32 %6, %6, %8\n v_and_b32 %7, %7, %8\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                : "v"(b));
+        } else if (MODE == 27) {  // INT32 multiply: v_mul_lo_u32 / v_mul_hi_u32
+            asm volatile(
+                "v_mul_lo_u32 %0, %0, %8\n v_mul_hi_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_hi_u32 %3, %3, %8\n"
+                "v_mul_lo_u32 %4, %4, %8\n v_mul_hi_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_hi_u32 %7, %7, %8\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                : "v"(b));
+        } else if (MODE == 28) {  // CVT: v_cvt_f32_u32 / v_cvt_u32_f32
+            asm volatile(
+                "v_cvt_f32_u32 %0, %0\n v_cvt_u32_f32 %1, %1\n v_cvt_f32_u32 %2, %2\n v_cvt_u32_f32 %3, %3\n"
+                "v_cvt_f32_u32 %4, %4\n v_cvt_u32_f32 %5, %5\n v_cvt_f32_u32 %6, %6\n v_cvt_u32_f32 %7, %7\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+        } else if (MODE == 29) {  // v_cndmask_b32 on vcc
+            asm volatile(
+                "v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                : "v"(b) : "vcc");
+        } else if (MODE == 30) {  // v_mov_b32
+            asm volatile(
+                "v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n"
+                "v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+        } else if (MODE == 31) {  // INT64-ish: v_lshlrev_b64 on pairs
+            asm volatile(
+                "v_lshlrev_b64 %0, 1, %0\n v_lshlrev_b64 %1, 1, %1\n v_lshlrev_b64 %2, 1, %2\n v_lshlrev_b64 %3, 1, %3\n"
+                "v_lshlrev_b64 %4, 1, %4\n v_lshlrev_b64 %5, 1, %5\n v_lshlrev_b64 %6, 1, %6\n v_lshlrev_b64 %7, 1, %7\n"
+                : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7));
+        } else if (MODE == 32) {  // v_mbcnt_lo / v_mbcnt_hi
+            asm volatile(
+                "v_mbcnt_lo_u32_b32 %0, -1, %0\n v_mbcnt_hi_u32_b32 %1, -1, %1\n v_mbcnt_lo_u32_b32 %2, -1, %2\n v_mbcnt_hi_u32_b32 %3, -1, %3\n"
+                "v_mbcnt_lo_u32_b32 %4, -1, %4\n v_mbcnt_hi_u32_b32 %5, -1, %5\n v_mbcnt_lo_u32_b32 %6, -1, %6\n v_mbcnt_hi_u32_b32 %7, -1, %7\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+        } else if (MODE == 33) {  // v_sub_f32 (ADD class) alone
+            asm volatile(
+                "v_sub_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_sub_f32 %2, %2, %8\n v_sub_f32 %3, %3, %8\n"
+                "v_sub_f32 %4, %4, %8\n v_sub_f32 %5, %5, %8\n v_sub_f32 %6, %6, %8\n v_sub_f32 %7, %7, %8\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                : "v"(b));
+        } else if (MODE == 34) {  // v_mul_f32 (MUL class) alone
+            asm volatile(
+                "v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                : "v"(b));
+        } else if (MODE == 35) {  // v_readlane_b32 into SGPRs (spilled-scalar reloads look like this)
+            unsigned m0, m1, m2, m3;
+            asm volatile(
+                "v_readlane_b32 %4, %0, 1\n v_readlane_b32 %5, %1, 2\n v_readlane_b32 %6, %2, 3\n v_readlane_b32 %7, %3, 4\n"
+                "v_readlane_b32 %4, %0, 5\n v_readlane_b32 %5, %1, 6\n v_readlane_b32 %6, %2, 7\n v_readlane_b32 %7, %3, 8\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3));
+            acc |= (m0 | m1) | (m2 | m3);
+        }
+
+        else if (MODE == 36) {  // v_cndmask_b32 e64 with an SGPR-pair mask
+            unsigned long long msk = 0x5555555555555555ull;
+            asm volatile(
+                "v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_cndmask_b32_e64 %3, %3, %8, %9\n"
+                "v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                : "v"(b), "s"(msk));
+        } else if (MODE == 37) {  // v_cmp_e32 -> vcc then v_cndmask on it (the compiler's usual select)
+            asm volatile(
+                "v_cmp_ge_f32_e32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_ge_f32_e32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                "v_cmp_ge_f32_e32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %8, vcc\n v_cmp_ge_f32_e32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                : "v"(b) : "vcc");
+        } else if (MODE == 38) {  // v_cndmask_b32 vcc, vcc defined once before the loop, different source / destination registers
+            asm volatile(
+                "v_cndmask_b32 %0, %1, %8, vcc\n v_cndmask_b32 %1, %2, %8, vcc\n v_cndmask_b32 %2, %3, %8, vcc\n v_cndmask_b32 %3, %4, %8, vcc\n"
+                "v_cndmask_b32 %4, %5, %8, vcc\n v_cndmask_b32 %5, %6, %8, vcc\n v_cndmask_b32 %6, %7, %8, vcc\n v_cndmask_b32 %7, %0, %8, vcc\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                : "v"(b) : "vcc");
+        } else if (MODE == 39) {  // v_min_f32 / v_max_f32 (not FMA / ADD / MUL class)
+            asm volatile(
+                "v_min_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_min_f32 %2, %2, %8\n v_max_f32 %3, %3, %8\n"
+                "v_min_f32 %4, %4, %8\n v_max_f32 %5, %5, %8\n v_min_f32 %6, %6, %8\n v_max_f32 %7, %7, %8\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                : "v"(b));
         }
         else if (MODE == 6) {  // SGPR in src0 of v_fma
             asm volatile(
@@ -294,6 +392,29 @@ int main()
     run_rate<21>("v_max_f32 VOP2", dout, n_cu, 1);
     run_rate<22>("v_max_f32_e64 |a|,|b|", dout, n_cu, 1);
     run_rate<23>("v_or3_b32 x4 + v_and_b32 x4", dout, n_cu, 1);
+    // Issue cost per instruction class, in the classes rocprofv3's SQ_INSTS_VALU_* counters report (bench.py weights the
+    // kernel's measured mix with these: roofline.frac).  Printed once more as one JSON line for tools/pmc_constants.py.
+    const double c_fma = run_rate<0>("class FMA_F32  v_fma_f32", dout, n_cu, 2);
+    const double c_add = run_rate<33>("class ADD_F32  v_sub_f32", dout, n_cu, 1);
+    const double c_mul = run_rate<34>("class MUL_F32  v_mul_f32", dout, n_cu, 1);
+    const double c_rcp = run_rate<24>("class TRANS_F32 v_rcp_f32", dout, n_cu, 1);
+    const double c_sqrt = run_rate<25>("class TRANS_F32 v_sqrt/v_rsq", dout, n_cu, 1);
+    const double c_int = run_rate<26>("class INT32 add/shift/and", dout, n_cu, 1);
+    const double c_imul = run_rate<27>("class INT32 v_mul_lo/hi_u32", dout, n_cu, 1);
+    const double c_cvt = run_rate<28>("class CVT v_cvt_f32_u32/u32_f32", dout, n_cu, 1);
+    run_rate<29>("other: v_cndmask_b32 vcc (in place)", dout, n_cu, 1);
+    run_rate<38>("other: v_cndmask_b32 vcc (rotating)", dout, n_cu, 1);
+    run_rate<37>("other: v_cmp_e32 + v_cndmask vcc", dout, n_cu, 1);
+    run_rate<39>("other: v_min_f32/v_max_f32", dout, n_cu, 1);
+    const double c_cnd = run_rate<36>("other: v_cndmask_b32_e64 sgpr mask", dout, n_cu, 1);
+    const double c_mov = run_rate<30>("other: v_mov_b32", dout, n_cu, 1);
+    const double c_i64 = run_rate<31>("class INT64 v_lshlrev_b64", dout, n_cu, 1);
+    const double c_mbc = run_rate<32>("other: v_mbcnt_lo/hi", dout, n_cu, 1);
+    const double c_cmp = run_rate<18>("other: v_cmp_e64", dout, n_cu, 1);
+    const double c_rdl = run_rate<35>("other: v_readlane_b32", dout, n_cu, 1);
+    printf("VALU_CLASS_CYCLES {\"FMA_F32\": %.3f, \"ADD_F32\": %.3f, \"MUL_F32\": %.3f, \"TRANS_F32\": %.3f, \"INT32\": %.3f, \"INT32_MUL\": %.3f, "
+           "\"CVT\": %.3f, \"INT64\": %.3f, \"OTHER\": %.3f, \"other_detail\": {\"cndmask\": %.3f, \"mov\": %.3f, \"mbcnt\": %.3f, \"cmp\": %.3f, \"readlane\": %.3f}}\n",
+           c_fma, c_add, c_mul, 0.5 * (c_rcp + c_sqrt), c_int, c_imul, c_cvt, c_i64, 0.25 * (c_cnd + c_mov + c_mbc + c_cmp), c_cnd, c_mov, c_mbc, c_cmp, c_rdl);
 
     // conformance
     const int n = 1 << 22;
