@@ -14,6 +14,7 @@ fn main() {
         .arg(&lib)
         .arg(csrc.join("rt_kernels.hip"))
         .arg(csrc.join("rt_pinhole.hip"))
+        .arg(csrc.join("rt_paths.hip"))
         .arg(csrc.join("rt_scratch.hip"))
         .arg(csrc.join("rt_capi.cpp"))
         .status()
@@ -21,7 +22,7 @@ fn main() {
     assert!(status.success(), "hipcc failed");
     // every prerequisite of csrc/Makefile's library rule (tests/test_abi.py compares the two lists)
     for f in [
-        "rt_kernels.hip", "rt_pinhole.hip", "rt_scratch.hip", "rt_capi.cpp", "rt_internal.h", "rt_device.h", "rt_complex.h",
+        "rt_kernels.hip", "rt_pinhole.hip", "rt_paths.hip", "rt_scratch.hip", "rt_capi.cpp", "rt_internal.h", "rt_device.h", "rt_complex.h",
         "rt_host_shapes.h", "rt_host_bvh.h", "rt_host_grid.h", "rt_grid.h",
     ] {
         println!("cargo:rerun-if-changed={}", csrc.join(f).display());

@@ -308,6 +308,13 @@ int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream,
             return rc;
         p.prim_table = ws.prim_table;
         HIP_TRY(rt::launch_pinhole(p, g_ctx.n_cu, g_ctx.device, stream));
+    } else if (rt::paths_kernel_serves(p)) {
+        p.grid_mode = rt::paths_grid_mode(p);
+        if (int rc = ensure_scratch(ws, ws.secq, ws.secq_bytes, g_ctx.secq, g_ctx.secq_bytes, rt::paths_secq_bytes(p, g_ctx.n_cu),
+                                    "the continuing-ray rings"))
+            return rc;
+        p.secq = ws.secq;
+        HIP_TRY(rt::launch_paths(p, g_ctx.n_cu, g_ctx.device, stream));
     } else {
         HIP_TRY(rt::launch_trace(p, g_ctx.n_cu, g_ctx.device, stream));
     }
@@ -578,6 +585,8 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     // uniform grid for the continuing rays of the Projector kernel (disabled for small or unsuitable scenes)
     rt::host::GridHost grid = rt::host::build_grid(sph_exact, sph_box, n_sph);
     if (grid.items.size() & 1) grid.items.push_back(0);  // the kernel copies the item list in whole words
+    rt::host::ClusterHost clusters;
+    if (grid.g.enabled && n_pad <= (uint32_t)rt::kTileSpheres) clusters = rt::host::build_clusters(sph_exact, n_sph);
 
     rt_scene* s = new rt_scene;
     rt::DevScene& d = s->dev;
@@ -608,6 +617,11 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     if (grid.g.enabled) {
         up(grid.cells, &d.grid.cells);
         up(grid.items, &d.grid.items);
+    }
+    d.n_clu = (uint32_t)clusters.bound.size();
+    if (d.n_clu) {
+        up(clusters.bound, &d.clu_bound);
+        up(clusters.items, &d.clu_items);
     }
     if (e != hipSuccess) {
         free_scene(s);

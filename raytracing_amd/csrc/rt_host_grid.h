@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <utility>
 #include <vector>
 
 #include "rt_internal.h"
@@ -156,6 +157,77 @@ inline GridHost build_grid(const std::vector<float4>& sph_exact, const std::vect
     g.n_cells = (uint32_t)n_cells;
     g.n_items = (uint32_t)total;
     g.enabled = 1;
+    return out;
+}
+
+// Clusters of the scan-path entries for the explicit-ray kernel's bundle cull (rt_paths.hip): the entries in Morton order of
+// their centres, kClusterSize at a time, each group with a bounding sphere {c, R}: R >= |p_j - c| + r_j for every member j.
+// The cull tests the (at most 64) cluster bounds first and only the members of those that pass.  Tables of up to 1,024
+// entries with finite data only (the caller builds clusters when the grid exists).
+constexpr uint32_t kClusterSize = 16;
+struct ClusterHost {
+    std::vector<float4> bound;    // [n_clu]
+    std::vector<uint16_t> items;  // [n_clu * kClusterSize], 0xffff = none
+};
+inline ClusterHost build_clusters(const std::vector<float4>& sph_exact, uint32_t n)
+{
+    ClusterHost out;
+    if (n == 0 || n > 1024) return out;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t j = 0; j < n; ++j) {
+        const double p[3] = {sph_exact[j].x, sph_exact[j].y, sph_exact[j].z};
+        for (int a = 0; a < 3; ++a) {
+            if (!std::isfinite(p[a]) || !std::isfinite((double)sph_exact[j].w)) return out;
+            lo[a] = std::min(lo[a], p[a]);
+            hi[a] = std::max(hi[a], p[a]);
+        }
+    }
+    auto spread = [](uint32_t v) {  // 10 bits -> every third bit
+        v &= 0x3ffu;
+        v = (v | (v << 16)) & 0x030000ffu;
+        v = (v | (v << 8)) & 0x0300f00fu;
+        v = (v | (v << 4)) & 0x030c30c3u;
+        v = (v | (v << 2)) & 0x09249249u;
+        return v;
+    };
+    // one scale for the three axes, so that Morton cells are cubes
+    const double ext = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), std::max(hi[2] - lo[2], 1e-300));
+    std::vector<std::pair<uint32_t, uint32_t>> order(n);
+    for (uint32_t j = 0; j < n; ++j) {
+        const double p[3] = {sph_exact[j].x, sph_exact[j].y, sph_exact[j].z};
+        uint32_t code = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double f = (p[a] - lo[a]) / ext * 1023.0;
+            code |= spread((uint32_t)std::min(std::max(f, 0.0), 1023.0)) << a;
+        }
+        order[j] = {code, j};
+    }
+    std::sort(order.begin(), order.end());
+    const uint32_t n_clu = (n + kClusterSize - 1) / kClusterSize;
+    out.bound.resize(n_clu);
+    out.items.assign((size_t)n_clu * kClusterSize, (uint16_t)0xffffu);
+    for (uint32_t c = 0; c < n_clu; ++c) {
+        const uint32_t k0 = c * kClusterSize, k1 = std::min(n, k0 + kClusterSize);
+        double ctr[3] = {0, 0, 0};
+        for (uint32_t k = k0; k < k1; ++k) {
+            const float4& e = sph_exact[order[k].second];
+            ctr[0] += e.x;
+            ctr[1] += e.y;
+            ctr[2] += e.z;
+        }
+        for (int a = 0; a < 3; ++a) ctr[a] /= (double)(k1 - k0);
+        const float cf[3] = {(float)ctr[0], (float)ctr[1], (float)ctr[2]};  // the centre the device sees
+        double R = 0.0;
+        for (uint32_t k = k0; k < k1; ++k) {
+            const float4& e = sph_exact[order[k].second];
+            const double dx = (double)e.x - cf[0], dy = (double)e.y - cf[1], dz = (double)e.z - cf[2];
+            R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)e.w));
+            out.items[(size_t)c * kClusterSize + (k - k0)] = (uint16_t)order[k].second;
+        }
+        float Rf = (float)(R * (1.0 + 1e-6));
+        if ((double)Rf < R) Rf = std::nextafter(Rf, std::numeric_limits<float>::infinity());
+        out.bound[c] = make_float4(cf[0], cf[1], cf[2], Rf);
+    }
     return out;
 }
 

@@ -92,6 +92,10 @@ struct DevScene {
     uint32_t first_box;  // the first of them (lowest object index): what a ray with an all-NaN direction hits (rt_device.h nan_ray)
     float c2max;  // >= max_j (|p_j|^2 + r_j^2), rounded up: magnitude bound used by the cull margin
     DevGrid grid;
+    // clusters of scan-path entries for the explicit-ray kernel's bundle cull (rt_host_grid.h build_clusters); n_clu == 0: none
+    const float4* clu_bound;    // [n_clu] {centre, radius}: radius >= |p_j - centre| + r_j for every member j
+    const uint16_t* clu_items;  // [n_clu * 16] entry indices, 0xffff = none
+    uint32_t n_clu;
 };
 
 // Host-precomputed generator constants (scene_config.rs:70-72, 96-97): the per-component divisions and the
@@ -166,6 +170,11 @@ size_t pinhole_secq_bytes(const TraceParams& p, int n_cu);
 size_t pinhole_table_bytes(const TraceParams& p);
 uint32_t pinhole_tile_shift(const TraceParams& p);  // cull tiles for this launch (TraceParams::tile_shift), 0 when they would not pay
 uint32_t pinhole_grid_mode(const TraceParams& p);  // how this launch's continuing rays find their spheres (TraceParams::grid_mode)
+// Explicit rays in, polylines out on the LDS-grid machinery (rt_paths.hip); secq must hold paths_secq_bytes(), grid_mode = paths_grid_mode().
+bool paths_kernel_serves(const TraceParams& p);
+uint32_t paths_grid_mode(const TraceParams& p);
+size_t paths_secq_bytes(const TraceParams& p, int n_cu);
+hipError_t launch_paths(const TraceParams& p, int n_cu, int device, hipStream_t stream);
 hipError_t launch_finalize(const unsigned long long* fb_q, float* fb, uint32_t* seg_count, uint64_t n_cells, uint32_t spp, hipStream_t stream);
 
 }  // namespace rt

@@ -1,0 +1,515 @@
+// rt_paths.hip — Scene::simulate_rays in its own call shape (scene.rs:39-106): explicit rays in, polylines out.
+//
+// paths_kernel is the Projector kernel's machinery (rt_pinhole.hip) without a generator: 512-thread blocks whose LDS holds the
+// scan-path table {p, r} and the uniform grid, one ray per lane, a per-wave ring of continuing rays in global memory.  A step of
+// a wave is either
+//   * a FRESH step: a batch of 64 consecutive rays of the caller's list.  Ray lists come out of the reference's generators in
+//     (i, j) order (scene_config.rs:74-75, 104-105), so the rays of a batch usually form a thin bundle.  The wave bounds the bundle
+//     (a cone around it and a slab through it, both measured on the rays themselves: bundle_of) and copies the table entries the
+//     bound can touch to a short LDS list (bundle_cull); every ray then runs the reference's own discriminant (sphere.rs:13-18)
+//     on the list, exactly as the grid walk does per cell.  A bundle that is not thin, or whose list overflows, walks the grid.
+//   * a CONTINUING step: up to 64 rays popped from the ring (rays that left a surface), grid walk as in the Projector kernel.
+// Every candidate is confirmed by confirm_batch with the reference's exact sequence, so nothing about a result depends on
+// which of the three ways (list, walk, table scan) found it.  Polyline vertices, vertex counts and the optional bounce
+// records are written as the path goes (same layout as trace_kernel, rt_kernels.hip).
+//
+// A call of a few million rays is a few dozen steps per wave, so what a step WAITS for matters as much as what it issues:
+// batches are drawn from the interleaved work counters two batches ahead and their rays are loaded one batch ahead, the
+// object-index lookup is skipped when nothing reads it, and the ring's stores are only waited for when the ring is read.
+// Measured on the 4.1 M-ray call (tools/bench_simulate.py): batches of 64 / 128 / 256 / 512 rays sharing one bound and list:
+// 0.47 / 0.54 / 0.63 / 0.90 ms -- a heavy batch (every ray enters the cloud and bounces eight times) is the unit one wave works
+// through alone at the end of the launch, and that tail grows with the batch; one work counter instead of 32: 0.69 ms; static
+// dealing (wave g takes batches g, g + W, ...): 0.58 ms.
+#include "rt_complex.h"
+#include "rt_grid.h"
+
+#include <cstdlib>
+
+namespace rt {
+namespace {
+
+// In-kernel stopwatch for one region per build (-DRT_DBG_PTIME=n, measurement builds only): lane 0 of every wave adds the
+// s_memtime deltas of region n to a sum that the kernel returns in place of the segment total.
+#ifdef RT_DBG_PTIME
+#define RT_P0(n) if (RT_DBG_PTIME == n) t_reg = __builtin_readcyclecounter();
+#define RT_P1(n) if (RT_DBG_PTIME == n && lane == 0) dbg += __builtin_readcyclecounter() - t_reg;
+#else
+#define RT_P0(n)
+#define RT_P1(n)
+#endif
+
+constexpr int kPathThreads = 512;
+constexpr unsigned kBundleCap = 48;  // list entries of a fresh step; a bundle that needs more walks the grid
+constexpr unsigned long long kNoBatch = ~0ull;
+
+// Constants of the general filter (table scan) for one ray; a dead slot fails every test.
+__device__ __forceinline__ void path_general_consts(ScanConsts<1>& c, F3 o, F3 d, float a, bool live, const DevScene& sc)
+{
+    const float rs = 1.0f / __builtin_sqrtf(a);
+    c.dh[0] = d * rs;
+    c.nod[0] = -dot(o, c.dh[0]);
+    const float oo = dot(o, o);
+    const float margin = kCullKappaU * (oo + sc.c2max);
+    c.s0[0] = live ? (oo - margin) : __builtin_inff();
+    c.pp[0] = f3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z);
+    if (!live) {
+        c.dh[0] = f3(0.f, 0.f, 0.f);
+        c.nod[0] = 0.0f;
+        c.pp[0] = f3(0.f, 0.f, 0.f);
+    }
+}
+
+// The bundle of a fresh step (wave-uniform).  Two bounds, both measured on the rays themselves, so neither depends on how the
+// caller ordered them:
+//   cone: apex o0 (midway between the first and the last live ray's origin), unit axis ax (between their directions), sine /
+//         cosine of a half angle that contains every ray's direction, rho = the largest distance of a ray origin from o0;
+//   slab: a unit normal nrm (the plane through o0 that holds the first and the last ray, as well as it can), rho_n = the largest
+//         |(o_i - o0) . nrm| and sig = the largest |d^_i . nrm|: a point o_i + s d^_i lies within rho_n + s sig of that plane.
+// The rays of a generator column (scene_config.rs:98-105: one origin, targets along a line) are coplanar, which the cone alone
+// does not see: it is as thick as the fan is long.  coherent == false: no usable bound.
+struct Bundle {
+    F3 o0, ax, nrm;
+    float s, c, rho, rho2, rho_n, sig;
+    bool coherent;
+};
+
+__device__ __forceinline__ float lane_value(float v, unsigned l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); }
+
+__device__ __forceinline__ F3 ray_o(const RtRay& r) { return f3(r.origin[0], r.origin[1], r.origin[2]); }
+__device__ __forceinline__ F3 ray_d(const RtRay& r) { return f3(r.direction[0], r.direction[1], r.direction[2]); }
+
+// The bundle of a batch, measured on its live rays (o, d, a = d . d per lane).  Rays with an all-NaN direction are not `live`
+// here (push_nan_rays settles them); every live ray has been admitted by the grid (finite, starts within its error budget).
+// Zero directions give NaN unit vectors, which every reduction drops: such rays hit nothing.
+__device__ __forceinline__ Bundle bundle_of(F3 o, F3 d, float a, bool live)
+{
+    Bundle b;
+    b.coherent = false;
+    const unsigned long long lm = __ballot(live);
+    if (!lm) return b;
+    const unsigned first = (unsigned)__builtin_ctzll(lm), last = 63u - (unsigned)__builtin_clzll(lm);
+    const F3 dh = d * __builtin_amdgcn_rsqf(a);  // unit direction to ~1 ulp
+    const F3 oF = f3(lane_value(o.x, first), lane_value(o.y, first), lane_value(o.z, first));
+    const F3 oL = f3(lane_value(o.x, last), lane_value(o.y, last), lane_value(o.z, last));
+    const F3 dF = f3(lane_value(dh.x, first), lane_value(dh.y, first), lane_value(dh.z, first));
+    const F3 dL = f3(lane_value(dh.x, last), lane_value(dh.y, last), lane_value(dh.z, last));
+    b.o0 = 0.5f * (oF + oL);
+    const F3 am = dF + dL;
+    b.ax = am * __builtin_amdgcn_rsqf(dot(am, am));
+    // the plane of the first and the last ray: spanned by the axis and by what separates the two (directions of a fan, origins of
+    // a parallel sheet); whatever comes out, rho_n and sig below are measured against it
+    const F3 sep = (dL - dF) + (oL - oF) * __builtin_amdgcn_rsqf(dot(oL - oF, oL - oF) + 1e-30f);
+    const F3 nn = cross(b.ax, sep);
+    const float n2 = dot(nn, nn);
+    b.nrm = n2 > 1e-12f ? nn * __builtin_amdgcn_rsqf(n2) : f3(0.f, 0.f, 0.f);  // no separation (one ray, identical rays): no slab
+    const F3 cr = cross(dh, b.ax), od = o - b.o0;
+    const float sine = sgpr(wave_max(live ? __builtin_amdgcn_sqrtf(dot(cr, cr)) : 0.0f));
+    const float cosmin = sgpr(wave_min(live ? dot(dh, b.ax) : 1.0f));
+    b.rho2 = sgpr(wave_max(live ? dot(od, od) : 0.0f)) * 1.0001f;
+    b.rho = __builtin_amdgcn_sqrtf(b.rho2) * 1.0001f;
+    b.rho_n = sgpr(wave_max(live ? __builtin_fabsf(dot(od, b.nrm)) : 0.0f)) * 1.0001f + 1e-6f * b.rho;
+    b.sig = sgpr(wave_max(live ? __builtin_fabsf(dot(dh, b.nrm)) : 0.0f)) * 1.0001f + 1e-6f;
+    // directions within 14.5 degrees of the axis and all in its half space; a zero or non-finite axis fails the compares
+    b.coherent = cosmin > 0.5f && sine <= 0.25f && dot(b.ax, b.ax) > 0.5f && dot(b.o0, b.o0) < __builtin_inff() && b.rho2 < __builtin_inff() &&
+                 dot(b.nrm, b.nrm) < 2.0f;
+    b.s = sine * 1.0001f + 1e-6f;  // rounding of the unit directions and of the products above: a few 1e-7
+    b.c = __builtin_amdgcn_sqrtf(1.0f - b.s * b.s) * 0.9999f;
+    return b;
+}
+
+// May a ray of the bundle reach entry {p, r}?
+// Cone: the rays lie within rho of the cone (apex o0, axis ax, half angle theta), so an entry is out of reach when its distance
+// from the cone exceeds r_eff + rho.  With q = p - o0, qa = q . ax, perp = the distance of p from the axis,
+// perp cos(theta) - qa sin(theta) never exceeds the distance of p from the cone (it is that distance where the nearest cone
+// point lies on the mantle, negative inside, and smaller than |q| where the apex is nearest).
+// Slab: a ray point within r_eff of p has s <= |q| + rho + r_eff, and lies within rho_n + s sig of the plane (o0, nrm); so the
+// entry is out of reach when |q . nrm| > r_eff + rho_n + (|q| + rho + r_eff) sig.
+// r_eff covers the rays whose float discriminant is non-negative although they pass outside the sphere: |fl(disc) - disc| <=
+// 25 u a L^2 with L = |o - p| <= |q| + rho, i.e. r_eff^2 = r^2 + 25 u L^2; the code allows 64 u * 3 (|q|^2 + rho^2)
+// >= 64 u L^2.  The bounds' own arithmetic (a dozen roundings relative to |q| + r + rho) is covered by the 1e-4 relative slop.
+// NaN passes.
+__device__ __forceinline__ bool bundle_pass(const Bundle& b, float4 e)
+{
+    const F3 q = f3(e.x - b.o0.x, e.y - b.o0.y, e.z - b.o0.z);
+    const float qq = dot(q, q), qa = dot(q, b.ax), qn = dot(q, b.nrm);
+    // v_sqrt_f32 (1 ulp) serves a bound with 1e-4 of slop; the correctly rounded square root costs fifteen instructions more
+    const float perp = __builtin_amdgcn_sqrtf(__builtin_fmaxf(qq - qa * qa, 0.0f));
+    const float reff = __builtin_amdgcn_sqrtf(e.w * e.w + (64.0f * 3.0f * 0x1p-24f) * (qq + b.rho2)) * 1.00001f;
+    const float R = reff + b.rho;
+    const float mag = (perp + __builtin_fabsf(qa)) + R;  // >= |q| + r_eff + rho
+    const float f = perp * b.c - qa * b.s;
+    const bool cone_out = f > R + 1e-4f * mag;
+    const bool slab_out = __builtin_fabsf(qn) > (reff + b.rho_n) + mag * (b.sig + 1e-4f);
+    return !(cone_out || slab_out);
+}
+
+// The table entries (LDS copy of sph_exact: {p, r}, a box as its bounding sphere) the bundle can reach -> list / idx.
+// Returns their number; more than kBundleCap: the list is incomplete.
+__device__ __forceinline__ unsigned bundle_cull(const Bundle& b, LdsGV4* table, unsigned n_sph, const DevScene& sc, float4* list, uint32_t* idx, unsigned lane)
+{
+    unsigned n = 0;
+    for (unsigned base = 0; base < n_sph; base += 128u) {  // two rows per trip: their LDS reads and square roots overlap
+        const unsigned k0 = base + lane, k1 = base + 64u + lane;
+        const float4 e0 = grid_sphere(table, k0 < n_sph ? k0 : 0u), e1 = grid_sphere(table, k1 < n_sph ? k1 : 0u);
+        const bool p0 = k0 < n_sph && bundle_pass(b, e0), p1 = k1 < n_sph && bundle_pass(b, e1);
+        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+        if (m0 | m1) {
+            const unsigned pos0 = n + mbcnt64(m0), pos1 = n + (unsigned)__builtin_popcountll(m0) + mbcnt64(m1);
+            if (p0 && pos0 < kBundleCap) {
+                list[pos0] = e0;
+                idx[pos0] = k0 | ((sc.n_box && sc.sph_box[k0].w != 0.0f) ? 0x8000u : 0u);
+            }
+            if (p1 && pos1 < kBundleCap) {
+                list[pos1] = e1;
+                idx[pos1] = k1 | ((sc.n_box && sc.sph_box[k1].w != 0.0f) ? 0x8000u : 0u);
+            }
+            n += (unsigned)__builtin_popcountll(m0) + (unsigned)__builtin_popcountll(m1);
+        }
+    }
+    return n;
+}
+
+// Every live ray against the list: the reference's discriminant (sphere.rs:13-18, the operations of sphere_first_t on the same
+// operands) decides which pairs go to the candidate queue; a box entry goes there unconditionally (the exact slab test decides).
+__device__ __forceinline__ void scan_bundle_list(const float4* list, const uint32_t* idx, unsigned n, F3 o, F3 d, float a, bool live, WaveLds<1>& w,
+                                                 const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane)
+{
+    for (unsigned k = 0; k < n; k += 2) {
+        const unsigned k1 = k + 1 < n ? k + 1 : k;
+        const float4 s0 = list[k], s1 = list[k1];
+        const uint32_t i0 = idx[k], i1 = idx[k1];
+        bool p0, p1;
+        {
+            const F3 lo = o - f3(s0.x, s0.y, s0.z);
+            const float half_b = dot(lo, d);
+            const float c = dot(lo, lo) - s0.w * s0.w;
+            const float disc = half_b * half_b - a * c;
+            p0 = live && ((i0 & 0x8000u) || !(disc < 0.0f));
+        }
+        {
+            const F3 lo = o - f3(s1.x, s1.y, s1.z);
+            const float half_b = dot(lo, d);
+            const float c = dot(lo, lo) - s1.w * s1.w;
+            const float disc = half_b * half_b - a * c;
+            p1 = live && k + 1 < n && ((i1 & 0x8000u) || !(disc < 0.0f));
+        }
+        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+        if (m0) push_candidates<1>(w, sc, m0, p0, 0u, i0 & 0x7fffu, head, tail, lane);
+        if (m1) push_candidates<1>(w, sc, m1, p1, 0u, i1 & 0x7fffu, head, tail, lane);
+    }
+}
+
+// GM = 0: small tables (no grid): LDS holds {p, K}, every step scans it with the general filter.
+// GM = 1: LDS holds {p, r}, the grid's cells and its item lists (bundle lists for fresh rays, grid walk for the others).
+template <int GM>
+__global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParams p)
+{
+    extern __shared__ float4 tiles[];
+    __shared__ WaveLds<1> wl[kPathThreads / 64];
+    __shared__ float4 list_all[kPathThreads / 64][GM == 1 ? kBundleCap : 1];
+    __shared__ uint32_t idx_all[kPathThreads / 64][GM == 1 ? kBundleCap : 1];
+
+    const unsigned lane = lane_id();
+    const unsigned wave = threadIdx.x >> 6;
+    WaveLds<1>& w = wl[wave];
+    DevScene sc = p.sc;
+    const unsigned n_pad = sc.n_sph_pad;
+    const DevGrid& grid = sc.grid;
+    const unsigned grid_words = GM == 1 ? grid.n_cells + ((grid.n_items + 1u) >> 1) : 0u;
+    uint32_t* grid_lds = reinterpret_cast<uint32_t*>(tiles + n_pad);
+    {
+        const float4* src = GM == 1 ? sc.sph_exact : sc.sph_cull;
+        for (unsigned k = threadIdx.x; k < n_pad; k += kPathThreads) tiles[k] = src[k];
+        if (GM == 1) {
+            const uint32_t* items32 = reinterpret_cast<const uint32_t*>(grid.items);  // padded to whole words by the host
+            for (unsigned k = threadIdx.x; k < grid_words; k += kPathThreads) grid_lds[k] = k < grid.n_cells ? grid.cells[k] : items32[k - grid.n_cells];
+        }
+    }
+    if (GM == 1) sc.sph_exact = tiles;  // confirm and shading read {p, r} from the LDS copy
+    // the object index of a scan-path hit is only looked up when something reads it (bounce records; planes to compare with)
+    const bool need_obj = p.records != nullptr || sc.n_pl != 0;
+    __syncthreads();
+
+    const unsigned gwave = blockIdx.x * (kPathThreads / 64) + wave;
+    uint32_t* ring = p.secq + (size_t)gwave * kSecFields * kSecCap;
+    unsigned sec_count = 0;  // wave-uniform
+    bool ring_dirty = false;  // entries pushed since the ring was last read (their stores may still be in flight)
+    unsigned long long my_segments = 0, dbg = 0;
+    const unsigned long long total_rays = p.cell_count;
+    const unsigned long long total_batches = (total_rays + 63ull) / 64ull;
+    const uint32_t max_b = p.st.max_bounces;
+    const uint64_t stride_pts = (uint64_t)max_b + 1;
+
+    // Work: batch b (rays 64 b .. 64 b + 63) belongs to work counter b % kUnitCounters; a wave starts at its own counter and moves
+    // on when one runs out, as in the Projector kernel.  `ticket` is a draw in flight (lane 0), `next_batch` the batch whose rays
+    // are in `pre` (loaded while the batch before it was traced).
+    unsigned ctr = gwave % kUnitCounters, ctr_done = 0;
+    unsigned ticket = 0;
+    auto draw = [&]() {
+        if (lane == 0) ticket = atomicAdd(reinterpret_cast<unsigned*>(p.next_unit + (size_t)ctr * kUnitCounterStride), 1u);
+    };
+    // the drawn batch, or kNoBatch when every counter has run out; leaves the following draw in flight
+    auto resolve = [&]() -> unsigned long long {
+        if (ctr_done == kUnitCounters) return kNoBatch;
+        unsigned long long b = (unsigned long long)__builtin_amdgcn_readfirstlane(ticket) * kUnitCounters + ctr;
+        while (b >= total_batches) {  // this counter has run out: on to the next one (only at the end of the launch)
+            ctr = (ctr + 1u) % kUnitCounters;
+            if (++ctr_done == kUnitCounters) return kNoBatch;
+            draw();
+            b = (unsigned long long)__builtin_amdgcn_readfirstlane(ticket) * kUnitCounters + ctr;
+        }
+        draw();
+        return b;
+    };
+    auto load_batch = [&](unsigned long long b) -> RtRay {
+        const unsigned long long m = b * 64ull + lane;
+        return p.rays[(b != kNoBatch && m < total_rays) ? m : 0ull];
+    };
+    draw();
+    unsigned long long next_batch = resolve();
+    RtRay pre = load_batch(next_batch);
+
+    for (;;) {
+        const bool fresh_left = next_batch != kNoBatch;
+        const bool do_sec = sec_count >= 64u || (!fresh_left && sec_count > 0);
+        if (!do_sec && !fresh_left) break;
+        unsigned long long t_reg = 0;
+        (void)t_reg;
+        RT_P0(1)  // region 1: the whole step
+        RT_P0(2)  // region 2: ray set-up (ray loads / ring pops)
+        F3 ro, rd;
+        float rior;
+        uint32_t rm, rb;
+        bool live;
+        if (!do_sec) {
+            // ---- fresh step: batch `next_batch`, whose rays arrived while the previous batch was traced ----
+            const unsigned long long m64 = next_batch * 64ull + lane;
+            live = m64 < total_rays;
+            rm = (uint32_t)m64;
+            ro = ray_o(pre);
+            rd = ray_d(pre);
+            rior = pre.current_ior;
+            rb = 0;
+            next_batch = resolve();        // waits for a draw made a whole batch ago; makes the next one
+            pre = load_batch(next_batch);  // in flight while this batch is traced
+        } else {
+            // ---- continuing step: up to 64 rays from the ring ----
+            const unsigned n_pop = sec_count < 64u ? sec_count : 64u;
+            const unsigned base = sec_count - n_pop;
+            sec_count = base;
+            // the ring is global memory that only this wave touches: its stores have to have landed before they are read back
+            if (ring_dirty) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            ring_dirty = false;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            live = lane < n_pop;
+            const unsigned e = base + (live ? lane : 0u);
+            ro = f3(__uint_as_float(ring[0 * kSecCap + e]), __uint_as_float(ring[1 * kSecCap + e]), __uint_as_float(ring[2 * kSecCap + e]));
+            rd = f3(__uint_as_float(ring[3 * kSecCap + e]), __uint_as_float(ring[4 * kSecCap + e]), __uint_as_float(ring[5 * kSecCap + e]));
+            rior = __uint_as_float(ring[6 * kSecCap + e]);
+            rm = ring[7 * kSecCap + e];
+            rb = ring[9 * kSecCap + e];
+        }
+        RT_P1(2)
+        RT_P0(3)  // region 3: scan (bound + list / walk / table) and confirm
+        const float a = dot(rd, rd);
+        w.stash[0][lane] = ro.x; w.stash[1][lane] = ro.y; w.stash[2][lane] = ro.z;
+        w.stash[3][lane] = rd.x; w.stash[4][lane] = rd.y; w.stash[5][lane] = rd.z;
+        w.stash[6][lane] = a;
+        w.best[lane] = kNoHit;
+        const bool scan_live = live && !nan_ray(rd);  // all-NaN directions are settled by push_nan_rays
+        unsigned head = 0, tail = 0;
+        wave_lds_sync();
+        push_nan_rays<1>(w, sc, live && !scan_live, 0u, head, tail, lane);
+
+        bool done = false;
+        if (GM == 1) {
+            // the grid (and the bundle bound) serve finite rays that start within the grid's error budget
+            const bool admitted = __ballot(scan_live && !grid_admits(grid, ro, rd)) == 0ull;
+            if (admitted && !do_sec) {
+                const Bundle bd = bundle_of(ro, rd, a, scan_live);
+#if RT_DBG_PATHS == 5
+                if (lane == 0 && !bd.coherent) ++dbg;
+#endif
+                if (bd.coherent) {
+                    const unsigned n = bundle_cull(bd, (LdsGV4*)tiles, sc.n_sph, sc, list_all[wave], idx_all[wave], lane);
+#if RT_DBG_PATHS == 3
+                    if (lane == 0) dbg += n;
+#endif
+#if RT_DBG_PATHS == 2
+                    if (lane == 0 && n > kBundleCap) ++dbg;
+#endif
+                    if (n <= kBundleCap) {
+                        wave_lds_sync();
+                        scan_bundle_list(list_all[wave], idx_all[wave], n, ro, rd, a, scan_live, w, sc, head, tail, lane);
+                        done = true;
+                    }
+                }
+            }
+            if (admitted && !done) {
+                grid_walk<1>(grid, (LdsU32*)grid_lds, (LdsU16*)(grid_lds + grid.n_cells), (LdsGV4*)tiles, ro, rd, a, scan_live, 0u, w, sc, head, tail, lane, dbg);
+                done = true;
+            }
+        }
+        if (!done) {
+            ScanConsts<1> c;
+            path_general_consts(c, ro, rd, a, scan_live, sc);
+            // GM == 1: the LDS table holds {p, r}, so this (rare) scan reads {p, K} from global memory with wave-uniform loads
+            scan_tile<1, 0, false>(GM == 1 ? sc.sph_cull : tiles, n_pad, nullptr, c, w, sc, head, tail, lane);
+        }
+
+        wave_lds_sync();
+        if (tail != head) confirm_batch<1>(w, sc, head, tail - head, lane);
+        wave_lds_sync();
+        RT_P1(3)
+        RT_P0(4)  // region 4: resolve, shade, outputs, ring push
+
+        // ---- planes, resolve, scatter (scene.rs:63-101), outputs ----
+        bool push = false;
+        Shade h;
+        h.o_next = ro; h.dn = rd; h.ior = rior;
+        if (live) {
+            int sj;
+            const unsigned long long kscan = scan_key(sc, w.best[lane], need_obj, sj);
+            const unsigned long long key = planes_min_key(sc, ro, rd, kscan);
+            ++my_segments;
+            const uint64_t path_id = p.path_id_base + rm;
+            float* pt = p.points + ((uint64_t)rm * stride_pts + rb) * 3;  // vertices rb and rb + 1 of the polyline
+            if (rb == 0) {  // scene.rs:45: the path starts with the ray's origin
+                pt[0] = ro.x; pt[1] = ro.y; pt[2] = ro.z;
+            }
+            RtBounceRecord rec;
+            bool path_done;
+            if (key != kNoHit) {
+                PreHit pre_hit;
+                pre_hit.valid = false;
+                h = shade_hit(sc, ro, rd, rior, key, p.seed, path_id, rb, pre_hit, key == kscan ? sj : -1);
+                pt[3] = h.point.x; pt[4] = h.point.y; pt[5] = h.point.z;
+                if (p.records) {
+                    rec.obj_id = h.obj; rec.t = h.t;
+                    rec.point[0] = h.point.x; rec.point[1] = h.point.y; rec.point[2] = h.point.z;
+                    rec.normal[0] = h.normal.x; rec.normal[1] = h.normal.y; rec.normal[2] = h.normal.z;
+                    rec.front_face = h.front ? 1u : 0u;
+                    rec.dir_out[0] = h.dn.x; rec.dir_out[1] = h.dn.y; rec.dir_out[2] = h.dn.z;
+                    rec.ior_out = h.ior;
+                    p.records[(uint64_t)rm * max_b + rb] = rec;
+                }
+                path_done = rb + 1 == max_b;  // bounce budget exhausted: the path ends at this hit
+                push = !path_done;
+            } else {
+                const F3 far = ro + rd * p.st.infinity_distance;  // scene.rs:99
+                pt[3] = far.x; pt[4] = far.y; pt[5] = far.z;
+                if (p.records) {
+                    rec.obj_id = -1; rec.t = __builtin_inff();
+                    rec.point[0] = far.x; rec.point[1] = far.y; rec.point[2] = far.z;
+                    rec.normal[0] = 0; rec.normal[1] = 0; rec.normal[2] = 0;
+                    rec.front_face = 0;
+                    rec.dir_out[0] = 0; rec.dir_out[1] = 0; rec.dir_out[2] = 0;
+                    rec.ior_out = rior;
+                    p.records[(uint64_t)rm * max_b + rb] = rec;
+                }
+                path_done = true;
+            }
+            if (path_done) p.n_points[rm] = rb + 2;
+        }
+        // append continuing rays to the ring (wave-uniform control flow); at most 63 + 64 entries are ever queued
+        const unsigned long long pm = __ballot(push);
+        if (pm) {
+            const unsigned e = sec_count + mbcnt64(pm);
+            if (push) {
+                ring[0 * kSecCap + e] = __float_as_uint(h.o_next.x);
+                ring[1 * kSecCap + e] = __float_as_uint(h.o_next.y);
+                ring[2 * kSecCap + e] = __float_as_uint(h.o_next.z);
+                ring[3 * kSecCap + e] = __float_as_uint(h.dn.x);
+                ring[4 * kSecCap + e] = __float_as_uint(h.dn.y);
+                ring[5 * kSecCap + e] = __float_as_uint(h.dn.z);
+                ring[6 * kSecCap + e] = __float_as_uint(h.ior);
+                ring[7 * kSecCap + e] = rm;
+                ring[9 * kSecCap + e] = rb + 1;
+            }
+            sec_count += (unsigned)__builtin_popcountll(pm);
+            ring_dirty = true;
+        }
+        RT_P1(4)
+        RT_P1(1)
+    }
+
+    if (p.total_segments) {
+#if defined(RT_DBG_PATHS) || defined(RT_DBG_PTIME)
+        unsigned long long v = dbg;
+#else
+        unsigned long long v = my_segments + 0 * dbg;
+#endif
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0 && v) atomicAdd(p.total_segments, v);
+    }
+}
+
+constexpr size_t kPathLdsPerBlock = 80 * 1024;  // two 512-thread blocks per CU share 160 KB
+inline size_t path_grid_bytes(const DevGrid& g) { return ((size_t)g.n_cells * 4 + ((size_t)g.n_items + 1) / 2 * 4 + 15) / 16 * 16; }
+
+template <int GM>
+int paths_blocks_per_cu(size_t dyn)
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, paths_kernel<GM>, kPathThreads, dyn) != hipSuccess || n < 1) n = 1;
+    return n;
+}
+
+}  // namespace
+
+// The explicit-ray kernel serves tables that fit an LDS tile and scenes without objects of the per-lane path (those, larger
+// tables and the exact-filter mode stay on trace_kernel).
+bool paths_kernel_serves(const TraceParams& p)
+{
+    return p.rays != nullptr && p.scan_mode == 0 && p.sc.n_cx == 0 && p.sc.n_sph_pad <= (uint32_t)kTileSpheres && p.points != nullptr && p.n_points != nullptr &&
+           !getenv("RT_HIP_NO_PATHS");
+}
+
+// 1: {p, r} + grid in LDS; 0: no grid (small table, or it does not fit beside the per-wave state)
+uint32_t paths_grid_mode(const TraceParams& p)
+{
+    if (!p.sc.grid.enabled || getenv("RT_HIP_NO_GRID")) return 0;
+    hipFuncAttributes fa{};
+    if (hipFuncGetAttributes(&fa, (const void*)paths_kernel<1>) != hipSuccess) return 0;
+    const size_t need = fa.sharedSizeBytes + (size_t)p.sc.n_sph_pad * sizeof(float4) + path_grid_bytes(p.sc.grid) + 512;
+    return need <= kPathLdsPerBlock ? 1u : 0u;
+}
+
+static size_t paths_dyn_lds(const TraceParams& p)
+{
+    return (size_t)p.sc.n_sph_pad * sizeof(float4) + (p.grid_mode == 1 ? path_grid_bytes(p.sc.grid) : 0);
+}
+
+static unsigned paths_grid(const TraceParams& p, int n_cu)
+{
+    const size_t dyn = paths_dyn_lds(p);
+    const uint64_t want = ((uint64_t)p.cell_count + kPathThreads - 1) / kPathThreads;
+    const int occ = p.grid_mode == 1 ? paths_blocks_per_cu<1>(dyn) : paths_blocks_per_cu<0>(dyn);
+    const uint64_t cap = (uint64_t)n_cu * occ;
+    const unsigned blocks = (unsigned)(want < cap ? want : cap);
+    return blocks ? blocks : 1;
+}
+
+size_t paths_secq_bytes(const TraceParams& p, int n_cu)
+{
+    return (size_t)paths_grid(p, n_cu) * (kPathThreads / 64) * kSecFields * kSecCap * sizeof(uint32_t);
+}
+
+hipError_t launch_paths(const TraceParams& p, int n_cu, int device, hipStream_t stream)
+{
+    static bool attr_set_dev[kMaxDevices] = {};  // function attributes are per device; callers hold the library mutex
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (!attr_set_dev[device]) {
+        hipError_t e = hipFuncSetAttribute((const void*)paths_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPathLdsPerBlock);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)paths_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPathLdsPerBlock);
+        if (e != hipSuccess) return e;
+        attr_set_dev[device] = true;
+    }
+    const unsigned grid = paths_grid(p, n_cu);
+    if (p.grid_mode == 1) hipLaunchKernelGGL((paths_kernel<1>), dim3(grid), dim3(kPathThreads), paths_dyn_lds(p), stream, p);
+    else hipLaunchKernelGGL((paths_kernel<0>), dim3(grid), dim3(kPathThreads), paths_dyn_lds(p), stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace rt

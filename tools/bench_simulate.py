@@ -12,6 +12,7 @@ from raytracing_amd.engine import SimulationSettingsConfig
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+limit = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # only the first `limit` rays (fixed cost of a call)
 engine.init(0)
 cfg = synth.config_c2(1920, 1080)
 g = cfg["gen"]
@@ -26,6 +27,8 @@ rays = np.zeros(len(d) * reps, abi.RAY_DTYPE)
 rays["origin"] = a
 rays["direction"] = np.tile(d, (reps, 1))
 rays["current_ior"] = 1.0
+if limit:
+    rays = rays[:limit].copy()
 n = len(rays)
 sc = engine.Scene(cfg["objects"])
 st = SimulationSettingsConfig(cfg["infinity_distance"], cfg["max_bounces"])
