@@ -456,6 +456,13 @@ __device__ __forceinline__ CullGeom cull_geom(const DevGen& g)
     const char __attribute__((address_space(4)))* name##_base = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr(); \
     asm volatile("" : "+s"(name##_base));                                                                                                  \
     const T __attribute__((address_space(4)))* name = reinterpret_cast<const T __attribute__((address_space(4)))*>(name##_base + (offset))
+// one scalar or pointer member
+template <typename T>
+__device__ __forceinline__ T kernarg_value(size_t offset)
+{
+    RT_KERNARG_PTR(T, vp, offset);
+    return *vp;
+}
 // (member by member: a whole-struct copy goes through private memory)
 __device__ __forceinline__ DevGen kernarg_gen(size_t offset)
 {

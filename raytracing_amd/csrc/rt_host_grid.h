@@ -164,7 +164,6 @@ inline GridHost build_grid(const std::vector<float4>& sph_exact, const std::vect
 // their centres, kClusterSize at a time, each group with a bounding sphere {c, R}: R >= |p_j - c| + r_j for every member j.
 // The cull tests the (at most 64) cluster bounds first and only the members of those that pass.  Tables of up to 1,024
 // entries with finite data only (the caller builds clusters when the grid exists).
-constexpr uint32_t kClusterSize = 16;
 struct ClusterHost {
     std::vector<float4> bound;    // [n_clu]
     std::vector<uint16_t> items;  // [n_clu * kClusterSize], 0xffff = none

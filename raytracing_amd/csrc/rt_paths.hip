@@ -128,19 +128,36 @@ __device__ __forceinline__ Bundle bundle_of(F3 o, F3 d, float a, bool live)
 // 25 u a L^2 with L = |o - p| <= |q| + rho, i.e. r_eff^2 = r^2 + 25 u L^2; the code allows 64 u * 3 (|q|^2 + rho^2)
 // >= 64 u L^2.  The bounds' own arithmetic (a dozen roundings relative to |q| + r + rho) is covered by the 1e-4 relative slop.
 // NaN passes.
-__device__ __forceinline__ bool bundle_pass(const Bundle& b, float4 e)
+__device__ __forceinline__ bool bundle_reach(const Bundle& b, F3 q, float qq, float reff)
 {
-    const F3 q = f3(e.x - b.o0.x, e.y - b.o0.y, e.z - b.o0.z);
-    const float qq = dot(q, q), qa = dot(q, b.ax), qn = dot(q, b.nrm);
+    const float qa = dot(q, b.ax), qn = dot(q, b.nrm);
     // v_sqrt_f32 (1 ulp) serves a bound with 1e-4 of slop; the correctly rounded square root costs fifteen instructions more
     const float perp = __builtin_amdgcn_sqrtf(__builtin_fmaxf(qq - qa * qa, 0.0f));
-    const float reff = __builtin_amdgcn_sqrtf(e.w * e.w + (64.0f * 3.0f * 0x1p-24f) * (qq + b.rho2)) * 1.00001f;
     const float R = reff + b.rho;
     const float mag = (perp + __builtin_fabsf(qa)) + R;  // >= |q| + r_eff + rho
     const float f = perp * b.c - qa * b.s;
     const bool cone_out = f > R + 1e-4f * mag;
     const bool slab_out = __builtin_fabsf(qn) > (reff + b.rho_n) + mag * (b.sig + 1e-4f);
     return !(cone_out || slab_out);
+}
+constexpr float kDiscSlop = 64.0f * 3.0f * 0x1p-24f;  // r_eff^2 = r^2 + kDiscSlop (|q|^2 + rho^2), see above
+__device__ __forceinline__ bool bundle_pass(const Bundle& b, float4 e)
+{
+    const F3 q = f3(e.x - b.o0.x, e.y - b.o0.y, e.z - b.o0.z);
+    const float qq = dot(q, q);
+    const float reff = __builtin_amdgcn_sqrtf(e.w * e.w + kDiscSlop * (qq + b.rho2)) * 1.00001f;
+    return bundle_reach(b, q, qq, reff);
+}
+// The same for a cluster {c, R} of entries (rt_host_grid.h build_clusters: R >= |p_j - c| + r_j for every member j).  A ray point
+// within r_eff_j of member j lies within r_eff_j + |p_j - c| of c, and r_eff_j <= r_j + sqrt(kDiscSlop (|q_j|^2 + rho^2)) with
+// |q_j| <= |q_c| + R: the cluster is out of reach when the sphere {c, R + sqrt(kDiscSlop ((|q_c| + R)^2 + rho^2))} is.
+__device__ __forceinline__ bool bundle_pass_cluster(const Bundle& b, float4 e)
+{
+    const F3 q = f3(e.x - b.o0.x, e.y - b.o0.y, e.z - b.o0.z);
+    const float qq = dot(q, q);
+    const float far = __builtin_amdgcn_sqrtf(qq) * 1.00001f + e.w;
+    const float reff = (e.w + __builtin_amdgcn_sqrtf(kDiscSlop * (far * far + b.rho2))) * 1.0001f;
+    return bundle_reach(b, q, qq, reff);
 }
 
 // The table entries (LDS copy of sph_exact: {p, r}, a box as its bounding sphere) the bundle can reach -> list / idx.
@@ -164,6 +181,40 @@ __device__ __forceinline__ unsigned bundle_cull(const Bundle& b, LdsGV4* table, 
                 idx[pos1] = k1 | ((sc.n_box && sc.sph_box[k1].w != 0.0f) ? 0x8000u : 0u);
             }
             n += (unsigned)__builtin_popcountll(m0) + (unsigned)__builtin_popcountll(m1);
+        }
+    }
+    return n;
+}
+
+// The same list through the clusters: one row of cluster bounds, then the members of the clusters that pass, four clusters (of
+// 16 entries) per row -- five rows or so for a thin bundle instead of the table's sixteen.  clu_bound / clu_items are LDS copies.
+__device__ __forceinline__ unsigned bundle_cull_clusters(const Bundle& b, LdsGV4* table, LdsGV4* clu_bound, LdsU16* clu_items, unsigned n_clu, const DevScene& sc,
+                                                         float4* list, uint32_t* idx, unsigned lane)
+{
+    unsigned long long m = __ballot(lane < n_clu && bundle_pass_cluster(b, grid_sphere(clu_bound, lane < n_clu ? lane : 0u)));
+    unsigned n = 0;
+    const unsigned slot = lane >> 4, member = lane & 15u;
+    while (m) {
+        unsigned c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c[k] = m ? (unsigned)__builtin_ctzll(m) : 0xffffu;
+            m &= m - 1ull;  // 0 stays 0
+        }
+        const unsigned mine = slot == 0 ? c[0] : slot == 1 ? c[1] : slot == 2 ? c[2] : c[3];
+        unsigned j = 0xffffu;
+        if (mine != 0xffffu) j = clu_items[mine * kClusterSize + member];
+        const bool have = j != 0xffffu;
+        const float4 e = grid_sphere(table, have ? j : 0u);
+        const bool pass = have && bundle_pass(b, e);
+        const unsigned long long pm = __ballot(pass);
+        if (pm) {
+            const unsigned pos = n + mbcnt64(pm);
+            if (pass && pos < kBundleCap) {
+                list[pos] = e;
+                idx[pos] = j | ((sc.n_box && sc.sph_box[j].w != 0.0f) ? 0x8000u : 0u);
+            }
+            n += (unsigned)__builtin_popcountll(pm);
         }
     }
     return n;
@@ -200,7 +251,8 @@ __device__ __forceinline__ void scan_bundle_list(const float4* list, const uint3
 }
 
 // GM = 0: small tables (no grid): LDS holds {p, K}, every step scans it with the general filter.
-// GM = 1: LDS holds {p, r}, the grid's cells and its item lists (bundle lists for fresh rays, grid walk for the others).
+// GM = 1: LDS holds {p, r}, the grid's cells and its item lists (bundle lists for fresh rays, grid walk for the others) and the
+//         clusters of the bundle cull.
 template <int GM>
 __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParams p)
 {
@@ -211,24 +263,45 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
 
     const unsigned lane = lane_id();
     const unsigned wave = threadIdx.x >> 6;
+#ifdef RT_DBG_TIMELINE  // measurement builds: per-wave timestamps (100 MHz wall clock) into the records buffer, tools/experiments/paths_timeline.py
+    unsigned long long tl[4] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0}, tl_steps = 0;
+#define RT_TL(k) tl[k] = __builtin_amdgcn_s_memrealtime();
+#else
+#define RT_TL(k)
+#endif
     WaveLds<1>& w = wl[wave];
     DevScene sc = p.sc;
     const unsigned n_pad = sc.n_sph_pad;
-    const DevGrid& grid = sc.grid;
-    const unsigned grid_words = GM == 1 ? grid.n_cells + ((grid.n_items + 1u) >> 1) : 0u;
+    const unsigned n_cells = sc.grid.n_cells;
+    const unsigned grid_words = GM == 1 ? n_cells + ((sc.grid.n_items + 1u) >> 1) : 0u;
     uint32_t* grid_lds = reinterpret_cast<uint32_t*>(tiles + n_pad);
     {
         const float4* src = GM == 1 ? sc.sph_exact : sc.sph_cull;
         for (unsigned k = threadIdx.x; k < n_pad; k += kPathThreads) tiles[k] = src[k];
         if (GM == 1) {
-            const uint32_t* items32 = reinterpret_cast<const uint32_t*>(grid.items);  // padded to whole words by the host
-            for (unsigned k = threadIdx.x; k < grid_words; k += kPathThreads) grid_lds[k] = k < grid.n_cells ? grid.cells[k] : items32[k - grid.n_cells];
+            const uint32_t* items32 = reinterpret_cast<const uint32_t*>(sc.grid.items);  // padded to whole words by the host
+            for (unsigned k = threadIdx.x; k < grid_words; k += kPathThreads) grid_lds[k] = k < n_cells ? sc.grid.cells[k] : items32[k - n_cells];
         }
+    }
+    // behind the grid: the clusters of the bundle cull, bounds first (16-byte aligned: the grid's words are padded to a multiple of 4)
+    const unsigned n_clu = GM == 1 ? sc.n_clu : 0u;
+    float4* clu_lds = reinterpret_cast<float4*>(grid_lds + ((grid_words + 3u) & ~3u));
+    uint32_t* clu_items_lds = reinterpret_cast<uint32_t*>(clu_lds + n_clu);
+    if (GM == 1 && n_clu) {
+        for (unsigned k = threadIdx.x; k < n_clu; k += kPathThreads) clu_lds[k] = sc.clu_bound[k];
+        const uint32_t* src32 = reinterpret_cast<const uint32_t*>(sc.clu_items);
+        for (unsigned k = threadIdx.x; k < n_clu * (kClusterSize / 2); k += kPathThreads) clu_items_lds[k] = src32[k];
     }
     if (GM == 1) sc.sph_exact = tiles;  // confirm and shading read {p, r} from the LDS copy
     // the object index of a scan-path hit is only looked up when something reads it (bounce records; planes to compare with)
-    const bool need_obj = p.records != nullptr || sc.n_pl != 0;
+#ifdef RT_DBG_TIMELINE
+    RtBounceRecord* const records = nullptr;  // the buffer takes the timestamps instead
+#else
+    RtBounceRecord* const records = p.records;
+#endif
+    const bool need_obj = records != nullptr || sc.n_pl != 0;
     __syncthreads();
+    RT_TL(1)
 
     const unsigned gwave = blockIdx.x * (kPathThreads / 64) + wave;
     uint32_t* ring = p.secq + (size_t)gwave * kSecFields * kSecCap;
@@ -283,6 +356,9 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
         bool live;
         if (!do_sec) {
             // ---- fresh step: batch `next_batch`, whose rays arrived while the previous batch was traced ----
+#ifdef RT_DBG_TIMELINE
+            tl_steps += 1ull;
+#endif
             const unsigned long long m64 = next_batch * 64ull + lane;
             live = m64 < total_rays;
             rm = (uint32_t)m64;
@@ -290,10 +366,17 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
             rd = ray_d(pre);
             rior = pre.current_ior;
             rb = 0;
+            // The rays of this batch are taken out of `pre` HERE, before the next batch's loads are issued.  Left to itself the
+            // compiler sinks these copies to the join behind the loads, where its wait for them (vmcnt counts in order) is a wait
+            // for the loads just issued (seen in the ISA: s_waitcnt vmcnt(0) two instructions after the global_load of the next batch).
+            asm volatile("" : "+v"(ro.x), "+v"(ro.y), "+v"(ro.z), "+v"(rd.x), "+v"(rd.y), "+v"(rd.z), "+v"(rior) : : "memory");
             next_batch = resolve();        // waits for a draw made a whole batch ago; makes the next one
             pre = load_batch(next_batch);  // in flight while this batch is traced
         } else {
             // ---- continuing step: up to 64 rays from the ring ----
+#ifdef RT_DBG_TIMELINE
+            tl_steps += 1ull << 16;
+#endif
             const unsigned n_pop = sec_count < 64u ? sec_count : 64u;
             const unsigned base = sec_count - n_pop;
             sec_count = base;
@@ -323,15 +406,22 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
 
         bool done = false;
         if (GM == 1) {
+            // this step's copy of the grid's constants (rt_device.h RT_KERNARG_PTR: read where used, not held through the loop)
+            const DevGrid grid = kernarg_grid(offsetof(TraceParams, sc) + offsetof(DevScene, grid));
             // the grid (and the bundle bound) serve finite rays that start within the grid's error budget
             const bool admitted = __ballot(scan_live && !grid_admits(grid, ro, rd)) == 0ull;
             if (admitted && !do_sec) {
+                RT_P0(5)  // region 5: the bundle's bound
                 const Bundle bd = bundle_of(ro, rd, a, scan_live);
+                RT_P1(5)
 #if RT_DBG_PATHS == 5
                 if (lane == 0 && !bd.coherent) ++dbg;
 #endif
                 if (bd.coherent) {
-                    const unsigned n = bundle_cull(bd, (LdsGV4*)tiles, sc.n_sph, sc, list_all[wave], idx_all[wave], lane);
+                    RT_P0(6)  // region 6: the cull
+                    const unsigned n = n_clu ? bundle_cull_clusters(bd, (LdsGV4*)tiles, (LdsGV4*)clu_lds, (LdsU16*)clu_items_lds, n_clu, sc, list_all[wave], idx_all[wave], lane)
+                                             : bundle_cull(bd, (LdsGV4*)tiles, sc.n_sph, sc, list_all[wave], idx_all[wave], lane);
+                    RT_P1(6)
 #if RT_DBG_PATHS == 3
                     if (lane == 0) dbg += n;
 #endif
@@ -340,13 +430,20 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
 #endif
                     if (n <= kBundleCap) {
                         wave_lds_sync();
+                        RT_P0(7)  // region 7: the list scan
                         scan_bundle_list(list_all[wave], idx_all[wave], n, ro, rd, a, scan_live, w, sc, head, tail, lane);
+                        RT_P1(7)
                         done = true;
                     }
                 }
             }
             if (admitted && !done) {
-                grid_walk<1>(grid, (LdsU32*)grid_lds, (LdsU16*)(grid_lds + grid.n_cells), (LdsGV4*)tiles, ro, rd, a, scan_live, 0u, w, sc, head, tail, lane, dbg);
+#ifdef RT_DBG_TIMELINE
+                if (!do_sec) tl_steps += 1ull << 32;
+#endif
+                RT_P0(8)  // region 8: the grid walk
+                grid_walk<1>(grid, (LdsU32*)grid_lds, (LdsU16*)(grid_lds + n_cells), (LdsGV4*)tiles, ro, rd, a, scan_live, 0u, w, sc, head, tail, lane, dbg);
+                RT_P1(8)
                 done = true;
             }
         }
@@ -358,8 +455,10 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
         }
 
         wave_lds_sync();
+        RT_P0(9)  // region 9: the last confirm batch
         if (tail != head) confirm_batch<1>(w, sc, head, tail - head, lane);
         wave_lds_sync();
+        RT_P1(9)
         RT_P1(3)
         RT_P0(4)  // region 4: resolve, shade, outputs, ring push
 
@@ -372,8 +471,8 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
             const unsigned long long kscan = scan_key(sc, w.best[lane], need_obj, sj);
             const unsigned long long key = planes_min_key(sc, ro, rd, kscan);
             ++my_segments;
-            const uint64_t path_id = p.path_id_base + rm;
-            float* pt = p.points + ((uint64_t)rm * stride_pts + rb) * 3;  // vertices rb and rb + 1 of the polyline
+            const uint64_t path_id = kernarg_value<uint64_t>(offsetof(TraceParams, path_id_base)) + rm;
+            float* pt = kernarg_value<float*>(offsetof(TraceParams, points)) + ((uint64_t)rm * stride_pts + rb) * 3;  // vertices rb and rb + 1 of the polyline
             if (rb == 0) {  // scene.rs:45: the path starts with the ray's origin
                 pt[0] = ro.x; pt[1] = ro.y; pt[2] = ro.z;
             }
@@ -382,40 +481,40 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
             if (key != kNoHit) {
                 PreHit pre_hit;
                 pre_hit.valid = false;
-                h = shade_hit(sc, ro, rd, rior, key, p.seed, path_id, rb, pre_hit, key == kscan ? sj : -1);
+                h = shade_hit(sc, ro, rd, rior, key, kernarg_value<uint64_t>(offsetof(TraceParams, seed)), path_id, rb, pre_hit, key == kscan ? sj : -1);
                 pt[3] = h.point.x; pt[4] = h.point.y; pt[5] = h.point.z;
-                if (p.records) {
+                if (records) {
                     rec.obj_id = h.obj; rec.t = h.t;
                     rec.point[0] = h.point.x; rec.point[1] = h.point.y; rec.point[2] = h.point.z;
                     rec.normal[0] = h.normal.x; rec.normal[1] = h.normal.y; rec.normal[2] = h.normal.z;
                     rec.front_face = h.front ? 1u : 0u;
                     rec.dir_out[0] = h.dn.x; rec.dir_out[1] = h.dn.y; rec.dir_out[2] = h.dn.z;
                     rec.ior_out = h.ior;
-                    p.records[(uint64_t)rm * max_b + rb] = rec;
+                    records[(uint64_t)rm * max_b + rb] = rec;
                 }
                 path_done = rb + 1 == max_b;  // bounce budget exhausted: the path ends at this hit
                 push = !path_done;
             } else {
-                const F3 far = ro + rd * p.st.infinity_distance;  // scene.rs:99
+                const F3 far = ro + rd * kernarg_value<float>(offsetof(TraceParams, st) + offsetof(RtSettings, infinity_distance));  // scene.rs:99
                 pt[3] = far.x; pt[4] = far.y; pt[5] = far.z;
-                if (p.records) {
+                if (records) {
                     rec.obj_id = -1; rec.t = __builtin_inff();
                     rec.point[0] = far.x; rec.point[1] = far.y; rec.point[2] = far.z;
                     rec.normal[0] = 0; rec.normal[1] = 0; rec.normal[2] = 0;
                     rec.front_face = 0;
                     rec.dir_out[0] = 0; rec.dir_out[1] = 0; rec.dir_out[2] = 0;
                     rec.ior_out = rior;
-                    p.records[(uint64_t)rm * max_b + rb] = rec;
+                    records[(uint64_t)rm * max_b + rb] = rec;
                 }
                 path_done = true;
             }
-            if (path_done) p.n_points[rm] = rb + 2;
+            if (path_done) kernarg_value<uint32_t*>(offsetof(TraceParams, n_points))[rm] = rb + 2;
         }
         // append continuing rays to the ring (wave-uniform control flow); at most 63 + 64 entries are ever queued
         const unsigned long long pm = __ballot(push);
         if (pm) {
             const unsigned e = sec_count + mbcnt64(pm);
-            if (push) {
+            if (push && e < kSecCap) {  // (always true: see above; a store outside the wave's ring must not happen whatever else goes wrong)
                 ring[0 * kSecCap + e] = __float_as_uint(h.o_next.x);
                 ring[1 * kSecCap + e] = __float_as_uint(h.o_next.y);
                 ring[2 * kSecCap + e] = __float_as_uint(h.o_next.z);
@@ -433,6 +532,20 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
         RT_P1(1)
     }
 
+#ifdef RT_DBG_TIMELINE
+    RT_TL(2)
+    {
+        unsigned long long v = my_segments;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0 && p.records) {
+            unsigned long long* out = reinterpret_cast<unsigned long long*>(p.records) + (size_t)gwave * 8;
+            out[0] = tl[0]; out[1] = tl[1]; out[2] = tl[2]; out[3] = tl[2]; out[4] = tl[2];
+            out[5] = v;
+            out[6] = 1;
+            out[7] = tl_steps;  // fresh steps | continuing steps << 16 | walked fresh steps << 32
+        }
+    }
+#endif
     if (p.total_segments) {
 #if defined(RT_DBG_PATHS) || defined(RT_DBG_PTIME)
         unsigned long long v = dbg;
@@ -446,7 +559,11 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
 }
 
 constexpr size_t kPathLdsPerBlock = 80 * 1024;  // two 512-thread blocks per CU share 160 KB
-inline size_t path_grid_bytes(const DevGrid& g) { return ((size_t)g.n_cells * 4 + ((size_t)g.n_items + 1) / 2 * 4 + 15) / 16 * 16; }
+inline size_t path_grid_bytes(const DevScene& sc)  // cells, items, cluster bounds, cluster items
+{
+    const DevGrid& g = sc.grid;
+    return ((size_t)g.n_cells * 4 + ((size_t)g.n_items + 1) / 2 * 4 + 15) / 16 * 16 + (size_t)sc.n_clu * (sizeof(float4) + kClusterSize * sizeof(uint16_t));
+}
 
 template <int GM>
 int paths_blocks_per_cu(size_t dyn)
@@ -472,13 +589,13 @@ uint32_t paths_grid_mode(const TraceParams& p)
     if (!p.sc.grid.enabled || getenv("RT_HIP_NO_GRID")) return 0;
     hipFuncAttributes fa{};
     if (hipFuncGetAttributes(&fa, (const void*)paths_kernel<1>) != hipSuccess) return 0;
-    const size_t need = fa.sharedSizeBytes + (size_t)p.sc.n_sph_pad * sizeof(float4) + path_grid_bytes(p.sc.grid) + 512;
+    const size_t need = fa.sharedSizeBytes + (size_t)p.sc.n_sph_pad * sizeof(float4) + path_grid_bytes(p.sc) + 512;
     return need <= kPathLdsPerBlock ? 1u : 0u;
 }
 
 static size_t paths_dyn_lds(const TraceParams& p)
 {
-    return (size_t)p.sc.n_sph_pad * sizeof(float4) + (p.grid_mode == 1 ? path_grid_bytes(p.sc.grid) : 0);
+    return (size_t)p.sc.n_sph_pad * sizeof(float4) + (p.grid_mode == 1 ? path_grid_bytes(p.sc) : 0);
 }
 
 static unsigned paths_grid(const TraceParams& p, int n_cu)
