@@ -298,6 +298,8 @@ int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream,
         }
         p.prim_margin = (float)(c2 * 64.0 * 0x1p-24 * (1.0 + 1e-6));
         p.grid_mode = rt::pinhole_grid_mode(p);  // decides the LDS layout, hence the resident blocks the rings are sized for
+        // the fixed workspace's rings hold 512 blocks of 8 waves: a device or build with more resident blocks launches 512
+        p.max_blocks = ws.fixed ? (uint32_t)(rt::kNoAllocRingBytes / (8 * rt::kSecFields * rt::kSecCap * sizeof(uint32_t))) : 0u;
         p.tile_shift = ws.fixed ? 0 : rt::pinhole_tile_shift(p);  // the fixed workspace has no room for tile lists: its calls cull the whole table
         if (int rc = ensure_scratch(ws, ws.secq, ws.secq_bytes, g_ctx.secq, g_ctx.secq_bytes, rt::pinhole_secq_bytes(p, g_ctx.n_cu),
                                     "the continuing-ray rings"))
@@ -404,11 +406,18 @@ int rt_hip_init(int device_ordinal)
         HIP_TRY(hipSetDevice(device_ordinal));
     }
     if (!g_ctx.ready) {
+        // (a failure half way leaves nothing behind: the next rt_hip_init starts from an empty context)
         HIP_TRY(hipMalloc((void**)&g_ctx.counters, kCounterRing * rt::kUnitCounterBytes));
-        HIP_TRY(hipEventCreateWithFlags(&g_ctx.last_done, hipEventDisableTiming));
+        hipError_t e = hipEventCreateWithFlags(&g_ctx.last_done, hipEventDisableTiming);
         // this device's copy of the no-alloc workspace (rt_scratch.hip); device_ordinal is current
         void* scratch = nullptr;
-        HIP_TRY(rt::noalloc_scratch_address(&scratch));
+        if (e == hipSuccess) e = rt::noalloc_scratch_address(&scratch);
+        if (e != hipSuccess) {
+            (void)hipFree(g_ctx.counters);
+            if (g_ctx.last_done) (void)hipEventDestroy(g_ctx.last_done);
+            g_ctx = Context{};
+            return fail_hip(e, "rt_hip_init");
+        }
         g_ctx.noalloc_scratch = static_cast<unsigned char*>(scratch);
         g_ctx.device = device_ordinal;
         g_ctx.n_cu = prop.multiProcessorCount;

@@ -140,6 +140,7 @@ struct TraceParams {
     uint32_t grid_mode;      // pinhole kernel: 0 no grid, 1 grid in LDS, 2 grid in global memory (pinhole_grid_mode, set before sizing)
     uint32_t tile_shift;     // pinhole kernel: a cull tile is 2^tile_shift consecutive work items (pinhole_tile_shift); 0 = no tile lists
     uint32_t* tile_lists;    // set by launch_pinhole: behind the shared-origin table in the same buffer
+    uint32_t max_blocks;     // pinhole kernel: launch at most this many blocks (0: as many as are resident); the fixed workspace's rings hold 512
 };
 
 // Work counters of the Projector kernel: batch b of 64 units belongs to counter b % kUnitCounters; one 128-byte line each.

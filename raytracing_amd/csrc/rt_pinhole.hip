@@ -654,7 +654,9 @@ unsigned pinhole_grid(const TraceParams& p, int n_cu)
     const bool cx = p.sc.n_cx > 0;
     const int occ = stream_mode(p) ? (cx ? pinhole_blocks_per_cu<true, true>(dyn) : pinhole_blocks_per_cu<true, false>(dyn))
                                    : (cx ? pinhole_blocks_per_cu<false, true>(dyn) : pinhole_blocks_per_cu<false, false>(dyn));
-    const uint64_t cap = (uint64_t)n_cu * occ;
+    uint64_t cap = (uint64_t)n_cu * occ;
+    // the persistent kernel gives the same results with any number of blocks: a caller whose rings hold fewer waves gets fewer blocks
+    if (p.max_blocks && cap > p.max_blocks) cap = p.max_blocks;
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     return blocks ? blocks : 1;
 }

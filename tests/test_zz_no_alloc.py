@@ -40,25 +40,71 @@ def _same(a, b):
     assert a[4] == b[4]
 
 
+def _buffers(count):
+    import torch
+
+    dev = torch.device("cuda", 0)
+    return (torch.full((count, 3), float("nan"), dtype=torch.float32, device=dev), torch.full((count,), -7, dtype=torch.int32, device=dev),
+            torch.full((count,), float("nan"), dtype=torch.float32, device=dev), torch.full((count,), 12345, dtype=torch.int32, device=dev),
+            torch.full((1,), -1, dtype=torch.int64, device=dev))
+
+
+def _call(scene, which, gen, spp, st, seed, begin, count, step, bufs):
+    import torch
+
+    fb, fid, ft, seg, tot = bufs
+    rc = getattr(lib(), which)(scene.handle, C.byref(gen), spp, st.as_c(), seed, begin, count, step, fb.data_ptr(), fid.data_ptr(), ft.data_ptr(),
+                               seg.data_ptr(), tot.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RtHipError(rc, lib().rt_hip_last_error().decode())
+
+
+def _host(bufs):
+    fb, fid, ft, seg, tot = bufs
+    return fb.cpu().numpy(), fid.cpu().numpy(), ft.cpu().numpy(), seg.cpu().numpy().astype(np.uint32), int(tot.item())
+
+
 def test_noalloc_entry_point_matches_render_dev(engine):
     import torch
 
     cfg = synth.config_c2(160, 90)
     st = SimulationSettingsConfig(cfg["infinity_distance"], cfg["max_bounces"])
-    sc = engine.Scene(cfg["objects"])
     n = 160 * 90
     # first call: the whole grid, 5 spp (ragged sample block); second call: a smaller, strided range, other spp and seed
     calls = [(cfg["gen"], 5, cfg["seed"], 0, n, 1), (cfg["gen"], 9, 77, 3, 1000, 7), (cfg["gen"], 1, 5, n - 1, 1, 1)]
-    want = [_render(sc, "rt_hip_render_dev", *c[:2], st, *c[2:]) for c in calls]
+    # A FRESH context: nothing an earlier test made rt_hip_render_dev allocate (rings, accumulators, tables) is there to fall
+    # back on, and the output buffers exist before the free-memory reading.  The no-alloc calls come first.
+    lib().rt_hip_shutdown()
+    engine.init(0)
+    sc = engine.Scene(cfg["objects"])
+    bufs = [_buffers(c[4]) for c in calls]
+    torch.cuda.synchronize()
     free_before = torch.cuda.mem_get_info()[0]
-    got = [_render(sc, "rt_hip_render_dev_noalloc", *c[:2], st, *c[2:]) for c in calls]
+    for c, b in zip(calls, bufs):
+        _call(sc, "rt_hip_render_dev_noalloc", *c[:2], st, *c[2:], b)
+    torch.cuda.synchronize()
+    free_after = torch.cuda.mem_get_info()[0]
+    assert free_after >= free_before - (1 << 20), f"the no-alloc entry point took {free_before - free_after} bytes of device memory"
+    got = [_host(b) for b in bufs]
+    want = [_render(sc, "rt_hip_render_dev", *c[:2], st, *c[2:]) for c in calls]
     for g, w in zip(got, want):
         _same(g, w)
     assert got[0][4] > 5 * n  # continuing rays took part
-    assert torch.cuda.mem_get_info()[0] >= free_before - (64 << 20)  # nothing grew beyond the test's own output buffers
     # the same again in the opposite order: results do not depend on what the workspace held before
     for c, w in reversed(list(zip(calls, want))):
         _same(_render(sc, "rt_hip_render_dev_noalloc", *c[:2], st, *c[2:]), w)
+
+
+def test_noalloc_launches_fit_the_fixed_rings_whatever_the_occupancy(engine, monkeypatch):
+    """The fixed workspace's rings hold 512 blocks; a build or device with more resident blocks per CU launches 512 (same result)."""
+    cfg = synth.config_c2(256, 144)
+    st = SimulationSettingsConfig(cfg["infinity_distance"], cfg["max_bounces"])
+    sc = engine.Scene(cfg["objects"])
+    args = (cfg["gen"], 8, st, cfg["seed"], 0, 256 * 144, 1)
+    want = _render(sc, "rt_hip_render_dev", *args)
+    monkeypatch.setenv("RT_HIP_BLOCKS_PER_CU", "4")  # 1,024 blocks on 256 CUs; read by the library at every launch
+    _same(_render(sc, "rt_hip_render_dev_noalloc", *args), want)
+    _same(_render(sc, "rt_hip_render_dev", *args), want)
 
 
 def test_noalloc_other_kernels(engine):
