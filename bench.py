@@ -368,7 +368,7 @@ def main():
         if sim is None:
             kernel = ("pinhole_kernel<1, %s, %s> (Projector render loop, one ray per lane)" % ("false" if n_sph <= 1024 else "true", "true" if name == "c3" else "false"))
         else:
-            kernel = "trace_kernel (explicit rays, polylines out: the call shape of scene.rs:39)"
+            kernel = "paths_kernel<1> (explicit rays in, polylines out: the call shape of scene.rs:39; rt_paths.hip)"
         roof = valu_roofline(pmc, stale, rates, render_ms, launches, share, segs_local, kernel)
         if sim is None and name != "c3":
             algorithmic = segs_local * FLOP_PER_TEST * n_sph / (render_ms * 1e-3) / 1e12
@@ -431,7 +431,7 @@ def main():
             sms = sum(a.elapsed_time(b) for a, b in sev) / n_calls
             ssegs = sj.segments()
             spmc, sstale = pmc_entry("simulate", {"rays": sj.n_total, "max_bounces": cfg["max_bounces"]})
-            sroof = valu_roofline(spmc, sstale, rates, sms, 1, 1.0, ssegs, "trace_kernel (explicit rays, polylines out)")
+            sroof = valu_roofline(spmc, sstale, rates, sms, 1, 1.0, ssegs, "paths_kernel<1> (explicit rays, polylines out)")
             out["config"]["secondary"] = {
                 "workload": f"Scene::simulate_rays call shape (scene.rs:39, rt_hip_simulate_dev): {sj.n_total} explicit rays on the same scene, polylines out",
                 "value": ssegs * n_calls / el / 1e6, "unit": "Mrays/s", "ms_per_call": el / n_calls * 1e3, "kernel_ms": sms,

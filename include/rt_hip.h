@@ -29,7 +29,7 @@ extern "C" {
 /* ---- error codes ---- */
 #define RT_OK 0
 #define RT_ERR_INVALID (-1)     /* bad argument (null pointer, zero count, unknown enum) */
-#define RT_ERR_UNSUPPORTED (-2) /* valid in the reference, beyond a limit of the GPU path (a CSG tree needing > 8 hits per list or > 4 stacked lists) */
+#define RT_ERR_UNSUPPORTED (-2) /* valid in the reference, beyond a limit of the GPU path (a CSG tree needing > 16 hits per list or > 6 stacked lists) */
 #define RT_ERR_HIP (-3)         /* a HIP runtime call failed; text in rt_hip_last_error() */
 #define RT_ERR_NOT_INIT (-4)    /* rt_hip_init() has not been called on this process */
 

@@ -87,29 +87,40 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
     const float ex = __builtin_fmaf(t0, d.x, o.x), ey = __builtin_fmaf(t0, d.y, o.y), ez = __builtin_fmaf(t0, d.z, o.z);
     const int dimx = (int)g.dim[0], dimy = (int)g.dim[1], dimz = (int)g.dim[2];
     // clamped as floats (fmax / fmin drop a NaN), so the conversion is defined for every lane, live or not
-    int cx = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf((ex - g.lo[0]) * g.inv_cell), 0.0f), (float)(dimx - 1));
-    int cy = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf((ey - g.lo[1]) * g.inv_cell), 0.0f), (float)(dimy - 1));
-    int cz = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf((ez - g.lo[2]) * g.inv_cell), 0.0f), (float)(dimz - 1));
+    const int cx = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf((ex - g.lo[0]) * g.inv_cell), 0.0f), (float)(dimx - 1));
+    const int cy = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf((ey - g.lo[1]) * g.inv_cell), 0.0f), (float)(dimy - 1));
+    const int cz = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf((ez - g.lo[2]) * g.inv_cell), 0.0f), (float)(dimz - 1));
     const int sx = d.x > 0.0f ? 1 : -1, sy = d.y > 0.0f ? 1 : -1, sz = d.z > 0.0f ? 1 : -1;
     float tmx = tdx < inf ? (g.lo[0] + (float)(cx + (sx > 0 ? 1 : 0)) * g.cell - o.x) * ivx : inf;
     float tmy = tdy < inf ? (g.lo[1] + (float)(cy + (sy > 0 ? 1 : 0)) * g.cell - o.y) * ivy : inf;
     float tmz = tdz < inf ? (g.lo[2] + (float)(cz + (sz > 0 ? 1 : 0)) * g.cell - o.z) * ivz : inf;
 
+    // The walk keeps its cell as one linear index and the cells left before the grid's faces as three 10-bit fields of one word:
+    // a step adds the stride of its axis and takes 1 from that axis' field (leaving the grid = stepping when the field is 0).
+    // (Three coordinates cost three selects, three range compares and two integer multiplies per step for the index.)
+    unsigned idx = ((unsigned)cz * (unsigned)dimy + (unsigned)cy) * (unsigned)dimx + (unsigned)cx;
+    const int ix = sx, iy = sy * dimx, iz = sz * dimx * dimy;
+    unsigned left = (unsigned)(sx > 0 ? dimx - 1 - cx : cx) | ((unsigned)(sy > 0 ? dimy - 1 - cy : cy) << 10) | ((unsigned)(sz > 0 ? dimz - 1 - cz : cz) << 20);
     float bound = inf;  // upper bound of the t that will win, from spheres already queued
     unsigned k = 0, cnt = 0, start = 0;
     {
         // The start cell's record, read here and not by a first pass that tests nothing (that pass was one in fourteen).
         // Every lane reads (the indices are clamped, so the address is valid whatever the lane holds) and inactive lanes drop the
-        // result: with the load under `if (active)` this compiler (ROCm 7.2 clang, -O1 and -O3 alike) produced a kernel that lost
-        // hits on half of the fuzz cases; the two forms mean the same.
+        // result.  Written as `if (active) { rec = cells[..]; start = ..; cnt = ..; }` the block is IDENTICAL to the one at the end of
+        // the loop below (k is 0 here too); ROCm 7.2's clang merges the two, the loop then has two entries, and the structuriser
+        // nests it inside a divergent loop (lanes that fetch a record / lanes that walk), where the walk's ballots, mbcnt ranks and
+        // 64-lane confirm batches run on a subset of the wave: candidates handed to absent lanes were never confirmed -- lost hits
+        // on half of the fuzz cases.  profiles/r03_walk_isa_if_vs_select.txt has both listings; tools/check_walk_isa.py (run by
+        // tests/test_walk_isa.py) reads the loop shape out of every build.  Rule: no two identical conditional blocks at the
+        // entry and at the latch of a loop that contains wave-level operations.
 #ifdef RT_GRID_ACTIVE_LOAD  // the form that lost hits (kept for the ISA comparison)
         if (active) {
-            const unsigned rec = cells[((unsigned)cz * (unsigned)dimy + (unsigned)cy) * (unsigned)dimx + (unsigned)cx];
+            const unsigned rec = cells[idx];
             start = rec & 0xfffffu;
             cnt = rec >> 20;
         }
 #else
-        const unsigned rec = cells[((unsigned)cz * (unsigned)dimy + (unsigned)cy) * (unsigned)dimx + (unsigned)cx];
+        const unsigned rec = cells[idx];
         start = active ? rec & 0xfffffu : 0u;
         cnt = active ? rec >> 20 : 0u;
 #endif
@@ -181,16 +192,16 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
                 ++dbg;
 #endif
                 const bool stepx = tmx <= tmy && tmx <= tmz, stepy = !stepx && tmy <= tmz, stepz = !stepx && !stepy;
-                cx += stepx ? sx : 0;
-                cy += stepy ? sy : 0;
-                cz += stepz ? sz : 0;
+                const unsigned one = stepx ? 1u : (stepy ? 1u << 10 : 1u << 20);  // 1 in the stepped axis' field
+                idx += (unsigned)(stepx ? ix : (stepy ? iy : iz));
                 tmx += stepx ? tdx : 0.0f;
                 tmy += stepy ? tdy : 0.0f;
                 tmz += stepz ? tdz : 0.0f;
-                if ((unsigned)cx >= (unsigned)dimx || (unsigned)cy >= (unsigned)dimy || (unsigned)cz >= (unsigned)dimz) active = false;
+                if ((left & (one * 0x3ffu)) == 0u) active = false;  // no cell left on that axis: the ray leaves the grid
+                left -= one;
             }
             if (active) {
-                const unsigned rec = cells[((unsigned)cz * (unsigned)dimy + (unsigned)cy) * (unsigned)dimx + (unsigned)cx];
+                const unsigned rec = cells[idx];
                 start = rec & 0xfffffu;
                 cnt = rec >> 20;
                 k = 0;

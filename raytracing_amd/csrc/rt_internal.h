@@ -15,8 +15,12 @@ constexpr int kUnroll = 4;          // spheres per scan step; sphere arrays are 
 
 // ---- objects off the scan path (rt_complex.h): post-order node programs evaluated per lane ----
 enum : uint32_t { CX_SPHERE = 0, CX_PLANE = 1, CX_BOX = 2, CX_INFCYL = 3, CX_INFCONE = 4, CX_UNION = 16, CX_INTERSECTION = 17, CX_DIFFERENCE = 18 };
-constexpr int kCxMaxHits = 8;  // hits a node's list may hold (checked when the scene is built)
-constexpr int kCxStack = 4;    // list stack depth of the post-order evaluation (checked likewise)
+#ifndef RT_CX_MAX_HITS
+#define RT_CX_MAX_HITS 16  // (8 / 4 until round 3; 16 / 6 and 32 / 8 measured the same on the template-like scene and on C3: the lists live in private memory)
+#define RT_CX_STACK 6
+#endif
+constexpr int kCxMaxHits = RT_CX_MAX_HITS;  // hits a node's list may hold (checked when the scene is built)
+constexpr int kCxStack = RT_CX_STACK;       // list stack depth of the post-order evaluation (checked likewise)
 struct CxNode {
     uint32_t kind, pad0, pad1, pad2;
     float4 a;  // sphere: centre, radius | plane: point | box: min | cylinder: axis point, radius | cone: vertex, cos^2

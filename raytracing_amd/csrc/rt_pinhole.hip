@@ -1,15 +1,21 @@
-// rt_pinhole.hip — the render loop specialised for RayGeneratorConfig::Projector (scene_config.rs:84-108):
-// every primary ray leaves the same origin O towards target(i, j) = corner + i us + j vs, so the primary closest-hit scan
-// (77 % of all segments on the C2 workload) reduces to an affine form in the cell indices per sphere,
-//   |A' + i B' + j C'| >= |target - O|,   {A, B, C} = (p - O) . {corner - O, us, vs},  ' = divided by sK,
-// with sK = sqrt(|p-O|^2 - r^2 - margin) precomputed per sphere when the block starts.
-// That is 3 VALU instructions per test instead of 8.
+// rt_pinhole.hip — the render loop specialised for RayGeneratorConfig::Projector (scene_config.rs:84-108): the bench kernel.
 //
-// Rays that hit something leave the primary stream: the scatter result (scene.rs:68-97) is appended to a
-// wave-private ring of continuing rays, and whenever a full wave of them (64*R) has collected, the wave runs
-// one general scan step for them (same code as trace_kernel).  Both step kinds therefore run with every lane
-// busy.  Path values of primary misses are summed per work unit in registers; continuing paths add their
-// value and segment count with global atomics when they end (fixed-point sums: order-independent).
+// Every primary ray leaves the same origin O towards target(i, j) = corner + i us + j vs, so "can this ray reach sphere p" is an
+// affine form in the cell indices, |A' + i B' + j C'| >= |target - O| with {A, B, C} = (p - O) . {corner - O, us, vs} / sK
+// (pinhole_table_kernel).  The kernel never runs that test over the whole table:
+//   * pinhole_tiles_kernel culls the table once per launch for every tile of 64 work items (the spheres ANY ray of the tile's
+//     cells can pass: the same expression bounded over the tile's box of cell indices);
+//   * a wave's 64 lanes hold work units (a cell and a block of its samples) of neighbouring cells; when their cells change, the
+//     wave culls its tiles' lists once more with its own tighter box into a <= 40-entry LDS list (cull_group), and every primary
+//     step tests only that list (scan_cull_list) -- on C2 0.4 entries on average, and a group whose list is empty skips stash, scan
+//     and confirm altogether.
+// One ray per lane (R = 1).  A step of a wave is either a PRIMARY step (every lane starts the next sample of its unit) or a
+// CONTINUING step: rays that hit something are scattered (scene.rs:68-97) and appended to the wave's ring in global memory, and
+// whenever 64 have collected the wave pops them and walks the uniform grid over the spheres (rt_grid.h; in LDS for tables of up to
+// 1,024 entries, else in global memory), falling back to the 8-instruction table filter only for rays the grid
+// does not admit.  Every candidate either way is confirmed with the reference's exact operation sequence (confirm_batch), so the
+// results are those of the reference's linear scan.  Work units come from 32 interleaved atomic counters in batches of 64;
+// per-cell sums are integers (order-independent), combined per wave in LDS before the global atomics (flush_cells).
 #include "rt_complex.h"
 #include "rt_grid.h"
 
@@ -29,8 +35,8 @@ namespace {
 #endif
 
 
-// 512 threads: 8 waves share the LDS tables, 2 blocks per CU = 4 waves per SIMD at 128 VGPRs (about ten of them spilled with one
-// ray per lane, RT_PIN_R = 1; 109 with two).  Measured alternatives (two rays per lane): 384 threads / 3 waves per
+// 512 threads: 8 waves share the LDS tables, 2 blocks per CU = 4 waves per SIMD at 128 VGPRs (none spilled with one ray per lane,
+// RT_PIN_R = 1, and packed-f32 code generation off; 109 with two rays per lane).  Measured alternatives (two rays per lane): 384 threads / 3 waves per
 // SIMD / 168 VGPRs and 256 threads / 2 waves per SIMD / 187 VGPRs without spills were both slower (C2 frame 9.9 ms and 7.7 ms
 // against 6.0 ms): the grid walk lives on occupancy, not on registers.
 #ifndef RT_PRIMARY_REUSE

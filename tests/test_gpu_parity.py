@@ -134,6 +134,39 @@ def test_edge_cases(engine):
     assert got[2]["obj_id"][0, 0] == 0
 
 
+def _sphere_union_nodes(n, param):
+    """Post-order nodes of ((s0 U s1) U s2) U ... : n sphere leaves, then n - 1 unions; the root is the last node."""
+    nodes = np.zeros(2 * n - 1, abi.NODE_DTYPE)
+    for k in range(n):
+        nodes[k]["shape"], nodes[k]["shape_param"] = abi.RT_SHAPE_SPHERE, param(k)
+    for k in range(n - 1):
+        nodes[n + k]["shape"], nodes[n + k]["a"], nodes[n + k]["b"] = abi.RT_SHAPE_UNION, (0 if k == 0 else n + k - 1), k + 1
+    return nodes
+
+
+def test_union_with_sixteen_hits_per_list(engine):
+    """csg.rs:9-75 has no limit on the hits a list holds; the GPU path's per-lane lists hold 16 (8 until round 3): a union of eight
+    concentric glass shells, rays through all of them (every list full), inside them and past them, against the oracle."""
+    from raytracing_amd.engine import tree_object
+
+    nodes = _sphere_union_nodes(8, lambda k: (1.0 + 0.5 * k, 0, 0, 0))
+    objs = np.array([tree_object(len(nodes) - 1, (0.5, -0.25, 0.0), abi.RT_MAT_GLASS, 1.3, rotation_y_deg=20.0), sphere((9, 0, 0), 1.0, abi.RT_MAT_MIRROR)],
+                    dtype=abi.OBJECT_DTYPE)
+    rays = random_rays(4000, seed=21, extent=(7.0, 7.0, 7.0))
+    # 200 of them from outside through (nearly) the common centre: all sixteen surfaces on one ray
+    rng = np.random.default_rng(2)
+    o = rng.standard_normal((200, 3)).astype(np.float32)
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * np.float32(9.0) + np.array([0.5, -0.25, 0.0], np.float32)
+    rays[:200] = make_rays(o, (np.array([0.5, -0.25, 0.0], np.float32) - o + 0.01 * rng.standard_normal((200, 3)).astype(np.float32)))
+    st = SimulationSettingsConfig(40.0, 6)
+    pts, npts, recs = engine.Scene(objs, nodes=nodes).simulate_rays_raw(st, rays=rays, seed=5)
+    opts, onpts, orecs, _ = ob.OracleScene(objs, nodes).simulate(rays, 40.0, 6, seed=5)
+    assert np.array_equal(npts, onpts)
+    assert_records_equal(recs, orecs, "union of eight shells")
+    assert same(pts, opts)
+    assert (recs["obj_id"][:, 0] == 0).sum() > 600 and np.all(recs["obj_id"][:200, 0] == 0)  # the shells were hit
+
+
 def test_unsupported_inputs_fail_loudly(engine):
     from raytracing_amd._lib import RtHipError
 
@@ -148,15 +181,11 @@ def test_unsupported_inputs_fail_loudly(engine):
     bad["shape"], bad["material_kind"] = abi.RT_SHAPE_SPHERE, 9
     with pytest.raises(RtHipError):
         engine.Scene(np.array([bad], dtype=abi.OBJECT_DTYPE))
-    # a union whose hit list could exceed the per-lane capacity is refused, not truncated
+    # a union whose hit list could exceed the per-lane capacity (16 hits) is refused, not truncated: nine nested spheres
     from raytracing_amd.engine import tree_object
-    nodes = np.zeros(9, abi.NODE_DTYPE)
-    for k in range(5):
-        nodes[k]["shape"], nodes[k]["shape_param"] = abi.RT_SHAPE_SPHERE, (1.0 + k, 0, 0, 0)
-    for k in range(4):
-        nodes[5 + k]["shape"], nodes[5 + k]["a"], nodes[5 + k]["b"] = abi.RT_SHAPE_UNION, (k if k == 0 else 4 + k), k + 1
+    nodes = _sphere_union_nodes(9, lambda k: (1.0 + k, 0, 0, 0))
     with pytest.raises(RtHipError) as e:
-        engine.Scene(np.array([tree_object(8, (0, 0, 0), abi.RT_MAT_MIRROR)], dtype=abi.OBJECT_DTYPE), nodes=nodes)
+        engine.Scene(np.array([tree_object(len(nodes) - 1, (0, 0, 0), abi.RT_MAT_MIRROR)], dtype=abi.OBJECT_DTYPE), nodes=nodes)
     assert e.value.code == abi.RT_ERR_UNSUPPORTED
     # meshes: index out of range, vertex index out of range, non-finite vertex, mesh shape inside a tree
     from raytracing_amd.engine import mesh_object
@@ -1033,3 +1062,71 @@ def test_work_unit_length_changes_nothing(engine, spp):
         for a, b in zip(got[:4], want[:4]):
             assert np.array_equal(a, b), unit
         assert got[4] == want[4], unit
+
+
+# ---- the explicit-ray kernel (rt_paths.hip): coherent batches take the bundle cull (clusters, short lists), the rest walk the grid ----
+
+def _fan_rays(origin, corner, u, v, nu, nv):
+    """Rays from one origin to an nu x nv grid of targets, column by column (the order scene_config.rs:98-105 produces)."""
+    i, j = np.meshgrid(np.arange(nu, dtype=np.float32), np.arange(nv, dtype=np.float32), indexing="ij")
+    t = np.asarray(corner, np.float32) + i[..., None] * (np.asarray(u, np.float32) / np.float32(nu)) + j[..., None] * (np.asarray(v, np.float32) / np.float32(nv))
+    d = (t - np.asarray(origin, np.float32)).reshape(-1, 3).astype(np.float32)
+    return make_rays(np.tile(np.asarray(origin, np.float32), (len(d), 1)), d)
+
+
+def _check_simulate(engine, objs, rays, inf_dist, max_b, what, monkeypatch=None):
+    (pts, npts, recs), (opts, onpts, orecs) = _simulate_both(engine, objs, rays, inf_dist, max_b)
+    assert np.array_equal(npts, onpts), what
+    assert_records_equal(recs, orecs, what)
+    assert same(pts, opts), what
+    if monkeypatch is not None:  # the general kernel (trace_kernel) gives the same bytes
+        monkeypatch.setenv("RT_HIP_NO_PATHS", "1")
+        pts2, npts2, recs2 = engine.Scene(objs).simulate_rays_raw(SimulationSettingsConfig(inf_dist, max_b), rays=rays, seed=7)
+        monkeypatch.delenv("RT_HIP_NO_PATHS")
+        assert np.array_equal(npts2, npts) and same(pts2, pts), what
+        assert_records_equal(recs2, recs, what)
+    return npts
+
+
+def test_explicit_ray_kernel_bundles_against_the_oracle(engine, monkeypatch):
+    """Thin fans and parallel sheets through the C2 cloud (grid, clusters and bundle lists in LDS), column ends inside a batch
+    (incoherent batches walk the grid), a fan along a row of 60 spheres (list overflow), rays that start inside spheres."""
+    cfg = synth.config_c2(1920, 1080)
+    objs = cfg["objects"]
+    g = cfg["gen"]
+    # a window of the C2 projector, 40 columns of 100 cells: batches of 64 straddle column ends
+    fan = _fan_rays(g.a[:], (np.array(g.corner[:]) + 0.45 * np.array(g.u[:]) + 0.4 * np.array(g.v[:])), np.array(g.u[:]) * 0.05, np.array(g.v[:]) * 0.2, 40, 100)
+    n = _check_simulate(engine, objs, fan, cfg["infinity_distance"], cfg["max_bounces"], "C2 fan", monkeypatch)
+    assert (n > 2).sum() > 200  # the window looks at spheres
+    # a parallel sheet (ParallelGrid-like), rows of 64
+    oi, oj = np.meshgrid(np.arange(64, dtype=np.float32), np.arange(48, dtype=np.float32), indexing="ij")
+    o = np.stack([-30 + 0.9 * oi.ravel(), -15 + 0.6 * oj.ravel(), np.full(oi.size, -80.0, np.float32)], 1).astype(np.float32)
+    sheet = make_rays(o, np.tile(np.array([[0.05, 0.02, 1.0]], np.float32), (len(o), 1)))
+    _check_simulate(engine, objs, sheet, cfg["infinity_distance"], cfg["max_bounces"], "C2 sheet")
+    # a row of 60 touching spheres seen end-on by a thin fan: more entries than a bundle list holds (the batch walks the grid),
+    # beside 200 random spheres so that the grid and the clusters exist
+    row = [sphere((0.0, 0.0, 2.0 * k), 1.0, (abi.RT_MAT_GLASS, abi.RT_MAT_MIRROR, abi.RT_MAT_HALF_MIRROR)[k % 3], 1.4 if k % 3 == 0 else 0.5) for k in range(60)]
+    objs2 = np.array(row + list(random_scene(200, 0, seed=9, extent=(30.0, 15.0, 60.0))), dtype=abi.OBJECT_DTYPE)
+    fan2 = _fan_rays((0.1, 0.2, -40.0), (-1.0, -1.0, 0.0), (2.0, 0, 0), (0, 2.0, 0), 16, 64)
+    _check_simulate(engine, objs2, fan2, 80.0, 10, "row of spheres", monkeypatch)
+    # origins inside a sphere of the cloud, directions in a narrow cone
+    inside = make_rays(np.tile(np.array([[0.0, 0.0, 0.3]], np.float32), (640, 1)),
+                       np.array([0, 0, 1], np.float32) + 0.02 * np.random.default_rng(4).standard_normal((640, 3)).astype(np.float32))
+    _check_simulate(engine, objs2, inside, 80.0, 10, "inside a sphere")
+
+
+def test_explicit_ray_kernel_boxes_planes_and_small_tables(engine, monkeypatch):
+    """Bundle lists with box entries (confirmed by the slab test), planes beside the scan path, and tables too small for a grid."""
+    from raytracing_amd.engine import shape_object
+
+    rng = np.random.default_rng(31)
+    objs = list(random_scene(400, 2, seed=17, extent=(25.0, 12.0, 25.0)))
+    for k in range(150):
+        pos = (rng.uniform(-1, 1, 3) * np.array([25.0, 12.0, 25.0])).astype(np.float32)
+        objs.insert(int(rng.integers(0, len(objs))), shape_object(abi.RT_SHAPE_BOX, tuple(rng.uniform(0.5, 3.0, 3)), pos, (abi.RT_MAT_GLASS, abi.RT_MAT_MIRROR)[k % 2], 1.5))
+    objs = np.array(objs, dtype=abi.OBJECT_DTYPE)
+    fan = _fan_rays((0.0, 1.0, -70.0), (-20.0, -10.0, -30.0), (40.0, 0, 0), (0, 20.0, 0), 48, 64)
+    _check_simulate(engine, objs, fan, 90.0, 8, "boxes and planes", monkeypatch)
+    small = np.array(list(random_scene(40, 1, seed=5)), dtype=abi.OBJECT_DTYPE)  # no grid: every step scans the LDS table
+    _check_simulate(engine, small, _fan_rays((0, 0, -40.0), (-15.0, -8.0, -10.0), (30.0, 0, 0), (0, 16.0, 0), 32, 64), 60.0, 8, "small table", monkeypatch)
+    _check_simulate(engine, small, random_rays(3000, seed=8), 60.0, 8, "small table, random rays")
