@@ -348,7 +348,10 @@ static int blocks_per_cu(K kernel)
 template <int MODE, bool STREAM, bool CX>
 static hipError_t launch_trace_t(const TraceParams& p, int n_cu, int device, hipStream_t stream)
 {
-    constexpr int R = 2;
+    // Two rays per lane share the wave-uniform work of a table scan; with objects of the per-lane path (CSG trees, rotated shapes,
+    // meshes) a lane's time goes into those, one ray after the other, and the calls that bring them are small: one ray per lane
+    // spreads them over twice the waves (template-like scene, 1,369 rays: 1.83 -> see DESIGN.md §7).
+    constexpr int R = CX ? 1 : 2;
     static int occ_dev[kMaxDevices] = {};  // per device (the query runs on the current device); callers hold the library mutex
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
     if (!occ_dev[device]) occ_dev[device] = blocks_per_cu(trace_kernel<R, MODE, STREAM, CX>);
