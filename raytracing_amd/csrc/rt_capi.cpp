@@ -39,8 +39,14 @@ struct Context {
     hipEvent_t last_done = nullptr;
     hipStream_t last_stream = nullptr;
     bool last_valid = false;
+    // device staging of the host-buffer entry points (rays in, polylines out): grow-only up to kStageKeepBytes, so that a call at
+    // the reference's own sizes (a few rays) costs no hipMalloc / hipFree (each hipFree waits for the device); guarded by g_stage_mu
+    unsigned char* stage = nullptr;
+    size_t stage_bytes = 0;
 };
 Context g_ctx;
+std::mutex g_stage_mu;  // taken before g_mu, for the whole of a host-buffer call
+constexpr size_t kStageKeepBytes = (size_t)256 << 20;  // larger calls allocate and free their own buffers
 constexpr unsigned kCounterRing = 64;  // per-launch sets of work counters (kUnitCounterBytes each), used round-robin
 
 int fail(int code, const std::string& msg)
@@ -401,6 +407,7 @@ int rt_hip_init(int device_ordinal)
         (void)hipFree(g_ctx.fb_q);
         (void)hipFree(g_ctx.secq);
         (void)hipFree(g_ctx.prim_table);
+        (void)hipFree(g_ctx.stage);
         if (g_ctx.last_done) (void)hipEventDestroy(g_ctx.last_done);
         g_ctx = Context{};
         HIP_TRY(hipSetDevice(device_ordinal));
@@ -436,6 +443,7 @@ void rt_hip_shutdown(void)
         (void)hipFree(g_ctx.fb_q);
         (void)hipFree(g_ctx.secq);
         (void)hipFree(g_ctx.prim_table);
+        (void)hipFree(g_ctx.stage);
         if (g_ctx.last_done) (void)hipEventDestroy(g_ctx.last_done);
         g_ctx = Context{};
     }
@@ -721,11 +729,34 @@ int rt_hip_simulate(const rt_scene* scene, const RtRay* rays, uint64_t n_rays, R
     uint32_t* d_np = nullptr;
     RtBounceRecord* d_rec = nullptr;
     int rc = RT_OK;
+    // one device block {rays | polylines | vertex counts | records}, each part 256-byte aligned: the context's staging buffer when
+    // it is (or may become) large enough, an allocation of this call's own otherwise
+    auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t rays_bytes = sizeof(RtRay) * n_rays, np_bytes = sizeof(uint32_t) * n_rays;
+    const size_t need = pad(rays_bytes) + pad(pts_bytes) + pad(np_bytes) + (out_records ? pad(rec_bytes) : 0);
+    std::lock_guard<std::mutex> stage_lk(g_stage_mu);
+    unsigned char* block = nullptr;
+    bool own_block = false;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (need <= kStageKeepBytes) {
+            if (g_ctx.stage_bytes < need) {
+                (void)hipFree(g_ctx.stage);
+                g_ctx.stage = nullptr;
+                g_ctx.stage_bytes = 0;
+                const size_t want = need < ((size_t)1 << 20) ? ((size_t)1 << 20) : need + need / 2;
+                HIP_TRY(hipMalloc((void**)&g_ctx.stage, want));
+                g_ctx.stage_bytes = want;
+            }
+            block = g_ctx.stage;
+        }
+    }
+    if (!block) {
+        HIP_TRY(hipMalloc((void**)&block, need));
+        own_block = true;
+    }
     auto cleanup = [&]() {
-        (void)hipFree(d_rays);
-        (void)hipFree(d_pts);
-        (void)hipFree(d_np);
-        (void)hipFree(d_rec);
+        if (own_block) (void)hipFree(block);
     };
 #define TRY_OR_CLEAN(expr)                       \
     do {                                         \
@@ -735,13 +766,13 @@ int rt_hip_simulate(const rt_scene* scene, const RtRay* rays, uint64_t n_rays, R
             return fail_hip(e_, #expr);          \
         }                                        \
     } while (0)
-    TRY_OR_CLEAN(hipMalloc((void**)&d_rays, sizeof(RtRay) * n_rays));
-    TRY_OR_CLEAN(hipMalloc((void**)&d_pts, pts_bytes));
-    TRY_OR_CLEAN(hipMalloc((void**)&d_np, sizeof(uint32_t) * n_rays));
-    if (out_records) TRY_OR_CLEAN(hipMalloc((void**)&d_rec, rec_bytes));
-    TRY_OR_CLEAN(hipMemcpy(d_rays, rays, sizeof(RtRay) * n_rays, hipMemcpyHostToDevice));
-    TRY_OR_CLEAN(hipMemset(d_pts, 0, pts_bytes));
-    if (d_rec) TRY_OR_CLEAN(hipMemset(d_rec, 0, rec_bytes));
+    d_rays = reinterpret_cast<RtRay*>(block);
+    d_pts = reinterpret_cast<float*>(block + pad(rays_bytes));
+    d_np = reinterpret_cast<uint32_t*>(block + pad(rays_bytes) + pad(pts_bytes));
+    if (out_records) d_rec = reinterpret_cast<RtBounceRecord*>(block + pad(rays_bytes) + pad(pts_bytes) + pad(np_bytes));
+    TRY_OR_CLEAN(hipMemcpy(d_rays, rays, rays_bytes, hipMemcpyHostToDevice));
+    // polylines (and records) beyond a path's last vertex read as zeros
+    TRY_OR_CLEAN(hipMemsetAsync(d_pts, 0, need - pad(rays_bytes), nullptr));
     rc = rt_hip_simulate_dev(scene, d_rays, n_rays, settings, seed, ray_id_base, d_pts, d_np, d_rec, nullptr, nullptr);
     if (rc != RT_OK) {
         cleanup();
@@ -749,7 +780,7 @@ int rt_hip_simulate(const rt_scene* scene, const RtRay* rays, uint64_t n_rays, R
     }
     TRY_OR_CLEAN(hipDeviceSynchronize());
     TRY_OR_CLEAN(hipMemcpy(out_points, d_pts, pts_bytes, hipMemcpyDeviceToHost));
-    TRY_OR_CLEAN(hipMemcpy(out_n_points, d_np, sizeof(uint32_t) * n_rays, hipMemcpyDeviceToHost));
+    TRY_OR_CLEAN(hipMemcpy(out_n_points, d_np, np_bytes, hipMemcpyDeviceToHost));
     if (d_rec) TRY_OR_CLEAN(hipMemcpy(out_records, d_rec, rec_bytes, hipMemcpyDeviceToHost));
     cleanup();
     return RT_OK;
