@@ -142,10 +142,15 @@ def valu_roofline(pmc, stale, rates, render_ms, launches, share, segs_local, ker
         "valu_class_mix": None if not mix else {c: mix.get(c, 0.0) / max(1.0, sum(mix.get(k, 0.0) for k in CLASSES)) for c in CLASSES},
         "valu_class_cycles": rates or None,
         "valu_insts_per_segment": None if insts is None or not segs_local else insts * share / segs_local,
-        "executed_fp32": None if flops is None else {"achieved": flops * share / sec / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                                                     "frac": flops * share / sec / 1e12 / PEAK_FP32_TFLOPS,
-                                                     "note": "SQ_INSTS_VALU_FLOPS_FP32 of the same pass: FP32 operations the kernel "
-                                                             "really executed, over the packed-FMA vector peak (north_star's 50 % bar)"},
+        # SQ_INSTS_VALU_FLOPS_FP32 counts per WAVE instruction (1 per add / mul, 2 per fma: it equals ADD + MUL + 2 FMA of the mix
+        # pass), so the operations executed are 64 x that with every lane counted, and x valu_lane_util for the lanes that were live
+        "executed_fp32": None if flops is None else {"achieved": 64.0 * flops * share / sec / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                                     "frac": 64.0 * flops * share / sec / 1e12 / PEAK_FP32_TFLOPS,
+                                                     "frac_live_lanes": None if lane is None else 64.0 * flops * share * lane / sec / 1e12 / PEAK_FP32_TFLOPS,
+                                                     "note": "64 lanes x SQ_INSTS_VALU_FLOPS_FP32 (+ _TRANS) of the same pass: FP32 operations the "
+                                                             "kernel really executed, over the packed-FMA vector peak (north_star's 50 % bar). "
+                                                             "Low by construction: half of the instructions are compares, selects, moves and "
+                                                             "integer work, and the reference's arithmetic allows no FMA contraction"},
         "frac_at_sustained_clock": None if not clk or achieved is None or ceiling is None else achieved / (ceiling * clk / CLOCK_GHZ),
         "sustained_clock_ghz": clk,
         "valu_issue_util": issue,

@@ -8,7 +8,7 @@ NEST: an outer loop that alternates between "lanes that fetch a record" and "lan
 lanes leave through the exec mask -- so the ballot, the mbcnt ranks and the 64-lane confirm run on a subset of the wave, and
 candidates handed to absent lanes are never confirmed (lost hits).
 
-usage: python tools/check_walk_isa.py [-DRT_GRID_ACTIVE_LOAD ...]   -> one line per kernel: depth of the loop that holds the item loads
+usage: [RT_CSRC_DIR=/path/to/csrc] python tools/check_walk_isa.py [-DRT_GRID_ACTIVE_LOAD ...]   -> one line per kernel: depth of the loop that holds the item loads
 exit code 1 if any kernel's walk is not a depth-2 inner loop
 """
 import os
@@ -18,7 +18,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "raytracing_amd", "csrc")
+CSRC = os.environ.get("RT_CSRC_DIR", os.path.join(ROOT, "raytracing_amd", "csrc"))  # RT_CSRC_DIR: another checkout's csrc (e.g. a git worktree of 6720931)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-w",
          "-S", "--cuda-device-only"]
 
