@@ -318,6 +318,7 @@ int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream,
         HIP_TRY(rt::launch_pinhole(p, g_ctx.n_cu, g_ctx.device, stream));
     } else if (rt::paths_kernel_serves(p)) {
         p.grid_mode = rt::paths_grid_mode(p);
+        p.max_blocks = ws.fixed ? (uint32_t)(rt::kNoAllocRingBytes / (8 * rt::kSecFields * rt::kSecCap * sizeof(uint32_t))) : 0u;
         if (int rc = ensure_scratch(ws, ws.secq, ws.secq_bytes, g_ctx.secq, g_ctx.secq_bytes, rt::paths_secq_bytes(p, g_ctx.n_cu),
                                     "the continuing-ray rings"))
             return rc;

@@ -253,7 +253,14 @@ __device__ __forceinline__ void scan_bundle_list(const float4* list, const uint3
 // GM = 0: small tables (no grid): LDS holds {p, K}, every step scans it with the general filter.
 // GM = 1: LDS holds {p, r}, the grid's cells and its item lists (bundle lists for fresh rays, grid walk for the others) and the
 //         clusters of the bundle cull.
-template <int GM>
+//
+// RENDER = true (round 3): the same kernel driven by a ray generator instead of a ray list -- the fast path of renders the Projector
+// kernel does not take (ParallelGrid, or a Projector whose target plane runs through its origin).  Work item m = cell * spp + sample of
+// the launch; a batch is 64 consecutive items, i.e. the samples of a few neighbouring cells (scene_config.rs:74-75: consecutive cells
+// lie along v), whose rays form the same kind of thin bundle as a slice of a ray list.  A path's value and segment count go to its
+// cell's integer sums when it ends (flush_cells) instead of vertices to a polyline; results are those of every other
+// render kernel, bit for bit (integer sums, ids by cell and sample).
+template <int GM, bool RENDER>
 __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParams p)
 {
     extern __shared__ float4 tiles[];
@@ -297,9 +304,9 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
 #ifdef RT_DBG_TIMELINE
     RtBounceRecord* const records = nullptr;  // the buffer takes the timestamps instead
 #else
-    RtBounceRecord* const records = p.records;
+    RtBounceRecord* const records = RENDER ? nullptr : p.records;
 #endif
-    const bool need_obj = records != nullptr || sc.n_pl != 0;
+    const bool need_obj = records != nullptr || sc.n_pl != 0 || (RENDER && p.first_id != nullptr);
     __syncthreads();
     RT_TL(1)
 
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
     unsigned sec_count = 0;  // wave-uniform
     bool ring_dirty = false;  // entries pushed since the ring was last read (their stores may still be in flight)
     unsigned long long my_segments = 0, dbg = 0;
-    const unsigned long long total_rays = p.cell_count;
+    const unsigned long long total_rays = RENDER ? (unsigned long long)p.cell_count * p.spp : p.cell_count;  // work items
     const unsigned long long total_batches = (total_rays + 63ull) / 64ull;
     const uint32_t max_b = p.st.max_bounces;
     const uint64_t stride_pts = (uint64_t)max_b + 1;
@@ -335,6 +342,7 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
         return b;
     };
     auto load_batch = [&](unsigned long long b) -> RtRay {
+        if (RENDER) return RtRay{};  // the generator makes the rays: nothing to fetch
         const unsigned long long m = b * 64ull + lane;
         return p.rays[(b != kNoBatch && m < total_rays) ? m : 0ull];
     };
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
         RT_P0(2)  // region 2: ray set-up (ray loads / ring pops)
         F3 ro, rd;
         float rior;
-        uint32_t rm, rb;
+        uint32_t rm, rb, rsample = 0;  // rm: the ray's index in the list, or (RENDER) its cell of the launch
         bool live;
         if (!do_sec) {
             // ---- fresh step: batch `next_batch`, whose rays arrived while the previous batch was traced ----
@@ -361,11 +369,24 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
 #endif
             const unsigned long long m64 = next_batch * 64ull + lane;
             live = m64 < total_rays;
-            rm = (uint32_t)m64;
-            ro = ray_o(pre);
-            rd = ray_d(pre);
-            rior = pre.current_ior;
             rb = 0;
+            if (RENDER) {
+                // item -> (cell, sample); a 64-bit division costs a few hundred instructions, so only launches that need one pay it
+                const unsigned long long item = live ? m64 : 0ull;
+                if ((total_rays >> 32) == 0) {
+                    rm = (uint32_t)item / p.spp;
+                    rsample = (uint32_t)item - rm * p.spp;
+                } else {
+                    rm = (uint32_t)(item / p.spp);
+                    rsample = (uint32_t)(item - (unsigned long long)rm * p.spp);
+                }
+                primary_ray(p, rm, ro, rd, rior);
+            } else {
+                rm = (uint32_t)m64;
+                ro = ray_o(pre);
+                rd = ray_d(pre);
+                rior = pre.current_ior;
+            }
             // The rays of this batch are taken out of `pre` HERE, before the next batch's loads are issued.  Left to itself the
             // compiler sinks these copies to the join behind the loads, where its wait for them (vmcnt counts in order) is a wait
             // for the loads just issued (seen in the ISA: s_waitcnt vmcnt(0) two instructions after the global_load of the next batch).
@@ -390,6 +411,7 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
             rd = f3(__uint_as_float(ring[3 * kSecCap + e]), __uint_as_float(ring[4 * kSecCap + e]), __uint_as_float(ring[5 * kSecCap + e]));
             rior = __uint_as_float(ring[6 * kSecCap + e]);
             rm = ring[7 * kSecCap + e];
+            if (RENDER) rsample = ring[8 * kSecCap + e];
             rb = ring[9 * kSecCap + e];
         }
         RT_P1(2)
@@ -466,6 +488,43 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
         bool push = false;
         Shade h;
         h.o_next = ro; h.dn = rd; h.ior = rior;
+        // RENDER: a path that ends adds its value and its segments to its cell
+        bool fl = false;
+        unsigned long long fx = 0, fy = 0, fz = 0;
+        if (RENDER) {
+            if (live) {
+                int sj;
+                const unsigned long long kscan = scan_key(sc, w.best[lane], need_obj, sj);
+                const unsigned long long key = planes_min_key(sc, ro, rd, kscan);
+                ++my_segments;
+                const uint64_t path_id = (p.cell_begin + (uint64_t)rm * p.cell_step) * (uint64_t)p.spp + rsample;
+                F3 value = f3(0.f, 0.f, 0.f);
+                if (rb == 0 && rsample == 0) {  // first hit of the cell's first sample
+                    if (p.first_id) p.first_id[rm] = key != kNoHit ? (int32_t)(uint32_t)key : -1;
+                    if (p.first_t) p.first_t[rm] = key != kNoHit ? __uint_as_float((uint32_t)(key >> 32)) : __builtin_inff();
+                }
+                if (key != kNoHit) {
+                    if (rb + 1 == max_b) {
+                        fl = true;  // bounce budget exhausted: value 0
+                    } else {
+                        PreHit pre_hit;
+                        pre_hit.valid = false;
+                        h = shade_hit(sc, ro, rd, rior, key, kernarg_value<uint64_t>(offsetof(TraceParams, seed)), path_id, rb, pre_hit, key == kscan ? sj : -1);
+                        push = true;
+                    }
+                } else {
+                    value = sky(rd);
+                    fl = true;
+                }
+                if (fl) {
+                    fx = quantize(value.x);
+                    fy = quantize(value.y);
+                    fz = quantize(value.z);
+                }
+            }
+            // (wave-uniform call; the stash and the best keys are dead from here to the next step's set-up)
+            flush_cells(p.fb_q, fl, rm, fx, fy, fz, (unsigned long long)rb + 1ull, reinterpret_cast<uint32_t*>(&w.stash[0][0]), lane);
+        } else
         if (live) {
             int sj;
             const unsigned long long kscan = scan_key(sc, w.best[lane], need_obj, sj);
@@ -523,6 +582,7 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
                 ring[5 * kSecCap + e] = __float_as_uint(h.dn.z);
                 ring[6 * kSecCap + e] = __float_as_uint(h.ior);
                 ring[7 * kSecCap + e] = rm;
+                if (RENDER) ring[8 * kSecCap + e] = rsample;
                 ring[9 * kSecCap + e] = rb + 1;
             }
             sec_count += (unsigned)__builtin_popcountll(pm);
@@ -565,30 +625,34 @@ inline size_t path_grid_bytes(const DevScene& sc)  // cells, items, cluster boun
     return ((size_t)g.n_cells * 4 + ((size_t)g.n_items + 1) / 2 * 4 + 15) / 16 * 16 + (size_t)sc.n_clu * (sizeof(float4) + kClusterSize * sizeof(uint16_t));
 }
 
-template <int GM>
+template <int GM, bool RENDER>
 int paths_blocks_per_cu(size_t dyn)
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, paths_kernel<GM>, kPathThreads, dyn) != hipSuccess || n < 1) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, paths_kernel<GM, RENDER>, kPathThreads, dyn) != hipSuccess || n < 1) n = 1;
     return n;
 }
 
 }  // namespace
 
 // The explicit-ray kernel serves tables that fit an LDS tile and scenes without objects of the per-lane path (those, larger
-// tables and the exact-filter mode stay on trace_kernel).
+// tables and the exact-filter mode stay on trace_kernel): ray lists with polylines out, and generator-driven renders (RENDER).
 bool paths_kernel_serves(const TraceParams& p)
 {
-    return p.rays != nullptr && p.scan_mode == 0 && p.sc.n_cx == 0 && p.sc.n_sph_pad <= (uint32_t)kTileSpheres && p.points != nullptr && p.n_points != nullptr &&
-           !getenv("RT_HIP_NO_PATHS");
+    if (p.scan_mode != 0 || p.sc.n_cx != 0 || p.sc.n_sph_pad > (uint32_t)kTileSpheres || getenv("RT_HIP_NO_PATHS")) return false;
+    if (p.rays != nullptr) return p.points != nullptr && p.n_points != nullptr;
+    return p.fb_q != nullptr && p.spp != 0;  // a render launch: cell_count * spp work items
 }
+
+static bool paths_render(const TraceParams& p) { return p.rays == nullptr; }
 
 // 1: {p, r} + grid in LDS; 0: no grid (small table, or it does not fit beside the per-wave state)
 uint32_t paths_grid_mode(const TraceParams& p)
 {
     if (!p.sc.grid.enabled || getenv("RT_HIP_NO_GRID")) return 0;
     hipFuncAttributes fa{};
-    if (hipFuncGetAttributes(&fa, (const void*)paths_kernel<1>) != hipSuccess) return 0;
+    const void* fn = paths_render(p) ? (const void*)paths_kernel<1, true> : (const void*)paths_kernel<1, false>;
+    if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return 0;
     const size_t need = fa.sharedSizeBytes + (size_t)p.sc.n_sph_pad * sizeof(float4) + path_grid_bytes(p.sc) + 512;
     return need <= kPathLdsPerBlock ? 1u : 0u;
 }
@@ -601,9 +665,13 @@ static size_t paths_dyn_lds(const TraceParams& p)
 static unsigned paths_grid(const TraceParams& p, int n_cu)
 {
     const size_t dyn = paths_dyn_lds(p);
-    const uint64_t want = ((uint64_t)p.cell_count + kPathThreads - 1) / kPathThreads;
-    const int occ = p.grid_mode == 1 ? paths_blocks_per_cu<1>(dyn) : paths_blocks_per_cu<0>(dyn);
-    const uint64_t cap = (uint64_t)n_cu * occ;
+    const uint64_t items = paths_render(p) ? (uint64_t)p.cell_count * p.spp : (uint64_t)p.cell_count;
+    const uint64_t want = (items + kPathThreads - 1) / kPathThreads;
+    const bool r = paths_render(p);
+    const int occ = p.grid_mode == 1 ? (r ? paths_blocks_per_cu<1, true>(dyn) : paths_blocks_per_cu<1, false>(dyn))
+                                     : (r ? paths_blocks_per_cu<0, true>(dyn) : paths_blocks_per_cu<0, false>(dyn));
+    uint64_t cap = (uint64_t)n_cu * occ;
+    if (p.max_blocks && cap > p.max_blocks) cap = p.max_blocks;  // a caller whose rings hold fewer waves (the fixed workspace)
     const unsigned blocks = (unsigned)(want < cap ? want : cap);
     return blocks ? blocks : 1;
 }
@@ -618,14 +686,23 @@ hipError_t launch_paths(const TraceParams& p, int n_cu, int device, hipStream_t 
     static bool attr_set_dev[kMaxDevices] = {};  // function attributes are per device; callers hold the library mutex
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
     if (!attr_set_dev[device]) {
-        hipError_t e = hipFuncSetAttribute((const void*)paths_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPathLdsPerBlock);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)paths_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPathLdsPerBlock);
-        if (e != hipSuccess) return e;
+        const void* fns[4] = {(const void*)paths_kernel<0, false>, (const void*)paths_kernel<1, false>, (const void*)paths_kernel<0, true>,
+                              (const void*)paths_kernel<1, true>};
+        for (const void* fn : fns) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPathLdsPerBlock);
+            if (e != hipSuccess) return e;
+        }
         attr_set_dev[device] = true;
     }
     const unsigned grid = paths_grid(p, n_cu);
-    if (p.grid_mode == 1) hipLaunchKernelGGL((paths_kernel<1>), dim3(grid), dim3(kPathThreads), paths_dyn_lds(p), stream, p);
-    else hipLaunchKernelGGL((paths_kernel<0>), dim3(grid), dim3(kPathThreads), paths_dyn_lds(p), stream, p);
+    const size_t dyn = paths_dyn_lds(p);
+    if (paths_render(p)) {
+        if (p.grid_mode == 1) hipLaunchKernelGGL((paths_kernel<1, true>), dim3(grid), dim3(kPathThreads), dyn, stream, p);
+        else hipLaunchKernelGGL((paths_kernel<0, true>), dim3(grid), dim3(kPathThreads), dyn, stream, p);
+    } else {
+        if (p.grid_mode == 1) hipLaunchKernelGGL((paths_kernel<1, false>), dim3(grid), dim3(kPathThreads), dyn, stream, p);
+        else hipLaunchKernelGGL((paths_kernel<0, false>), dim3(grid), dim3(kPathThreads), dyn, stream, p);
+    }
     return hipGetLastError();
 }
 
