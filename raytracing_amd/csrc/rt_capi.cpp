@@ -604,7 +604,7 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     rt::host::GridHost grid = rt::host::build_grid(sph_exact, sph_box, n_sph);
     if (grid.items.size() & 1) grid.items.push_back(0);  // the kernel copies the item list in whole words
     rt::host::ClusterHost clusters;
-    if (grid.g.enabled && n_pad <= (uint32_t)rt::kTileSpheres) clusters = rt::host::build_clusters(sph_exact, n_sph);
+    if (grid.g.enabled && n_sph <= rt::kClusterMaxEntries) clusters = rt::host::build_clusters(sph_exact, n_sph);
 
     rt_scene* s = new rt_scene;
     rt::DevScene& d = s->dev;

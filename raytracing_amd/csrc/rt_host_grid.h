@@ -162,8 +162,8 @@ inline GridHost build_grid(const std::vector<float4>& sph_exact, const std::vect
 
 // Clusters of the scan-path entries for the explicit-ray kernel's bundle cull (rt_paths.hip): the entries in Morton order of
 // their centres, kClusterSize at a time, each group with a bounding sphere {c, R}: R >= |p_j - c| + r_j for every member j.
-// The cull tests the (at most 64) cluster bounds first and only the members of those that pass.  Tables of up to 1,024
-// entries with finite data only (the caller builds clusters when the grid exists).
+// The cull tests the cluster bounds first (64 per row) and only the members of those that pass.  Tables of up to kClusterMaxEntries
+// entries (48 bytes of LDS per cluster) with finite data only (the caller builds clusters when the grid exists).
 struct ClusterHost {
     std::vector<float4> bound;    // [n_clu]
     std::vector<uint16_t> items;  // [n_clu * kClusterSize], 0xffff = none
@@ -171,7 +171,7 @@ struct ClusterHost {
 inline ClusterHost build_clusters(const std::vector<float4>& sph_exact, uint32_t n)
 {
     ClusterHost out;
-    if (n == 0 || n > 1024) return out;
+    if (n == 0 || n > kClusterMaxEntries) return out;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (uint32_t j = 0; j < n; ++j) {
         const double p[3] = {sph_exact[j].x, sph_exact[j].y, sph_exact[j].z};

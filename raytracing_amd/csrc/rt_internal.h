@@ -152,6 +152,7 @@ constexpr unsigned kUnitCounters = 32;
 constexpr unsigned kUnitCounterStride = 16;  // in 64-bit words
 constexpr size_t kUnitCounterBytes = (size_t)kUnitCounters * kUnitCounterStride * sizeof(unsigned long long);  // 4,096
 
+constexpr uint32_t kClusterMaxEntries = 16384;  // 1,024 clusters = 48 KB of LDS in the explicit-ray kernel's global-grid mode
 constexpr uint32_t kClusterSize = 16;  // entries per cluster of the explicit-ray kernel's bundle cull (rt_host_grid.h build_clusters)
 
 constexpr unsigned kSecCap = 256;    // entries per wave ring (a primary step adds <= 64 R to a residue < 64 R; R <= 2 rays per lane)

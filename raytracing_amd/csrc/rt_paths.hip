@@ -188,33 +188,38 @@ __device__ __forceinline__ unsigned bundle_cull(const Bundle& b, LdsGV4* table, 
 
 // The same list through the clusters: one row of cluster bounds, then the members of the clusters that pass, four clusters (of
 // 16 entries) per row -- five rows or so for a thin bundle instead of the table's sixteen.  clu_bound / clu_items are LDS copies.
-__device__ __forceinline__ unsigned bundle_cull_clusters(const Bundle& b, LdsGV4* table, LdsGV4* clu_bound, LdsU16* clu_items, unsigned n_clu, const DevScene& sc,
+template <typename SphPtr>
+__device__ __forceinline__ unsigned bundle_cull_clusters(const Bundle& b, SphPtr table, LdsGV4* clu_bound, LdsU16* clu_items, unsigned n_clu, const DevScene& sc,
                                                          float4* list, uint32_t* idx, unsigned lane)
 {
-    unsigned long long m = __ballot(lane < n_clu && bundle_pass_cluster(b, grid_sphere(clu_bound, lane < n_clu ? lane : 0u)));
     unsigned n = 0;
     const unsigned slot = lane >> 4, member = lane & 15u;
-    while (m) {
-        unsigned c[4];
+    for (unsigned base = 0; base < n_clu; base += 64u) {  // one row of cluster bounds per 64 clusters (1,024 entries)
+        const unsigned c_mine = base + lane;
+        unsigned long long m = __ballot(c_mine < n_clu && bundle_pass_cluster(b, grid_sphere(clu_bound, c_mine < n_clu ? c_mine : 0u)));
+        while (m) {
+            unsigned c[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            c[k] = m ? (unsigned)__builtin_ctzll(m) : 0xffffu;
-            m &= m - 1ull;  // 0 stays 0
-        }
-        const unsigned mine = slot == 0 ? c[0] : slot == 1 ? c[1] : slot == 2 ? c[2] : c[3];
-        unsigned j = 0xffffu;
-        if (mine != 0xffffu) j = clu_items[mine * kClusterSize + member];
-        const bool have = j != 0xffffu;
-        const float4 e = grid_sphere(table, have ? j : 0u);
-        const bool pass = have && bundle_pass(b, e);
-        const unsigned long long pm = __ballot(pass);
-        if (pm) {
-            const unsigned pos = n + mbcnt64(pm);
-            if (pass && pos < kBundleCap) {
-                list[pos] = e;
-                idx[pos] = j | ((sc.n_box && sc.sph_box[j].w != 0.0f) ? 0x8000u : 0u);
+            for (int k = 0; k < 4; ++k) {
+                c[k] = m ? base + (unsigned)__builtin_ctzll(m) : 0xffffffffu;
+                m &= m - 1ull;  // 0 stays 0
             }
-            n += (unsigned)__builtin_popcountll(pm);
+            const unsigned mine = slot == 0 ? c[0] : slot == 1 ? c[1] : slot == 2 ? c[2] : c[3];
+            // (read as whole words: tools/check_walk_isa.py finds the grid walk by its 16-bit loads, the only ones in these kernels)
+            unsigned j = 0xffffu;
+            if (mine != 0xffffffffu) j = (reinterpret_cast<LdsU32*>(clu_items)[(mine * kClusterSize + member) >> 1] >> ((member & 1u) * 16u)) & 0xffffu;
+            const bool have = j != 0xffffu;
+            const float4 e = grid_sphere(table, have ? j : 0u);
+            const bool pass = have && bundle_pass(b, e);
+            const unsigned long long pm = __ballot(pass);
+            if (pm) {
+                const unsigned pos = n + mbcnt64(pm);
+                if (pass && pos < kBundleCap) {
+                    list[pos] = e;
+                    idx[pos] = j | ((sc.n_box && sc.sph_box[j].w != 0.0f) ? 0x8000u : 0u);
+                }
+                n += (unsigned)__builtin_popcountll(pm);
+            }
         }
     }
     return n;
@@ -253,6 +258,8 @@ __device__ __forceinline__ void scan_bundle_list(const float4* list, const uint3
 // GM = 0: small tables (no grid): LDS holds {p, K}, every step scans it with the general filter.
 // GM = 1: LDS holds {p, r}, the grid's cells and its item lists (bundle lists for fresh rays, grid walk for the others) and the
 //         clusters of the bundle cull.
+// GM = 2: tables beyond an LDS tile (more than 1,024 scan-path entries): nothing is staged; every ray, fresh or continuing, walks the grid
+//         in global memory (cells, items and {p, r} come through L2, as in the streamed Projector kernel).
 //
 // RENDER = true (round 3): the same kernel driven by a ray generator instead of a ray list -- the fast path of renders the Projector
 // kernel does not take (ParallelGrid, or a Projector whose target plane runs through its origin).  Work item m = cell * spp + sample of
@@ -265,8 +272,8 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
 {
     extern __shared__ float4 tiles[];
     __shared__ WaveLds<1> wl[kPathThreads / 64];
-    __shared__ float4 list_all[kPathThreads / 64][GM == 1 ? kBundleCap : 1];
-    __shared__ uint32_t idx_all[kPathThreads / 64][GM == 1 ? kBundleCap : 1];
+    __shared__ float4 list_all[kPathThreads / 64][GM != 0 ? kBundleCap : 1];
+    __shared__ uint32_t idx_all[kPathThreads / 64][GM != 0 ? kBundleCap : 1];
 
     const unsigned lane = lane_id();
     const unsigned wave = threadIdx.x >> 6;
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
     const unsigned n_cells = sc.grid.n_cells;
     const unsigned grid_words = GM == 1 ? n_cells + ((sc.grid.n_items + 1u) >> 1) : 0u;
     uint32_t* grid_lds = reinterpret_cast<uint32_t*>(tiles + n_pad);
-    {
+    if (GM != 2) {
         const float4* src = GM == 1 ? sc.sph_exact : sc.sph_cull;
         for (unsigned k = threadIdx.x; k < n_pad; k += kPathThreads) tiles[k] = src[k];
         if (GM == 1) {
@@ -291,10 +298,11 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
         }
     }
     // behind the grid: the clusters of the bundle cull, bounds first (16-byte aligned: the grid's words are padded to a multiple of 4)
-    const unsigned n_clu = GM == 1 ? sc.n_clu : 0u;
-    float4* clu_lds = reinterpret_cast<float4*>(grid_lds + ((grid_words + 3u) & ~3u));
+    // (GM = 2: the clusters are all the dynamic LDS holds)
+    const unsigned n_clu = GM != 0 ? sc.n_clu : 0u;
+    float4* clu_lds = GM == 2 ? tiles : reinterpret_cast<float4*>(grid_lds + ((grid_words + 3u) & ~3u));
     uint32_t* clu_items_lds = reinterpret_cast<uint32_t*>(clu_lds + n_clu);
-    if (GM == 1 && n_clu) {
+    if (GM != 0 && n_clu) {
         for (unsigned k = threadIdx.x; k < n_clu; k += kPathThreads) clu_lds[k] = sc.clu_bound[k];
         const uint32_t* src32 = reinterpret_cast<const uint32_t*>(sc.clu_items);
         for (unsigned k = threadIdx.x; k < n_clu * (kClusterSize / 2); k += kPathThreads) clu_items_lds[k] = src32[k];
@@ -427,12 +435,12 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
         push_nan_rays<1>(w, sc, live && !scan_live, 0u, head, tail, lane);
 
         bool done = false;
-        if (GM == 1) {
+        if (GM != 0) {
             // this step's copy of the grid's constants (rt_device.h RT_KERNARG_PTR: read where used, not held through the loop)
             const DevGrid grid = kernarg_grid(offsetof(TraceParams, sc) + offsetof(DevScene, grid));
             // the grid (and the bundle bound) serve finite rays that start within the grid's error budget
             const bool admitted = __ballot(scan_live && !grid_admits(grid, ro, rd)) == 0ull;
-            if (admitted && !do_sec) {
+            if ((GM == 1 || n_clu != 0u) && admitted && !do_sec) {
                 RT_P0(5)  // region 5: the bundle's bound
                 const Bundle bd = bundle_of(ro, rd, a, scan_live);
                 RT_P1(5)
@@ -441,8 +449,10 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
 #endif
                 if (bd.coherent) {
                     RT_P0(6)  // region 6: the cull
-                    const unsigned n = n_clu ? bundle_cull_clusters(bd, (LdsGV4*)tiles, (LdsGV4*)clu_lds, (LdsU16*)clu_items_lds, n_clu, sc, list_all[wave], idx_all[wave], lane)
-                                             : bundle_cull(bd, (LdsGV4*)tiles, sc.n_sph, sc, list_all[wave], idx_all[wave], lane);
+                    unsigned n;
+                    if (GM == 2) n = bundle_cull_clusters(bd, sc.sph_exact, (LdsGV4*)clu_lds, (LdsU16*)clu_items_lds, n_clu, sc, list_all[wave], idx_all[wave], lane);
+                    else if (n_clu) n = bundle_cull_clusters(bd, (LdsGV4*)tiles, (LdsGV4*)clu_lds, (LdsU16*)clu_items_lds, n_clu, sc, list_all[wave], idx_all[wave], lane);
+                    else n = bundle_cull(bd, (LdsGV4*)tiles, sc.n_sph, sc, list_all[wave], idx_all[wave], lane);
                     RT_P1(6)
 #if RT_DBG_PATHS == 3
                     if (lane == 0) dbg += n;
@@ -464,7 +474,8 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
                 if (!do_sec) tl_steps += 1ull << 32;
 #endif
                 RT_P0(8)  // region 8: the grid walk
-                grid_walk<1>(grid, (LdsU32*)grid_lds, (LdsU16*)(grid_lds + n_cells), (LdsGV4*)tiles, ro, rd, a, scan_live, 0u, w, sc, head, tail, lane, dbg);
+                if (GM == 2) grid_walk<1>(grid, grid.cells, grid.items, sc.sph_exact, ro, rd, a, scan_live, 0u, w, sc, head, tail, lane, dbg);
+                else grid_walk<1>(grid, (LdsU32*)grid_lds, (LdsU16*)(grid_lds + n_cells), (LdsGV4*)tiles, ro, rd, a, scan_live, 0u, w, sc, head, tail, lane, dbg);
                 RT_P1(8)
                 done = true;
             }
@@ -472,8 +483,8 @@ __global__ __launch_bounds__(kPathThreads, 4) void paths_kernel(const TraceParam
         if (!done) {
             ScanConsts<1> c;
             path_general_consts(c, ro, rd, a, scan_live, sc);
-            // GM == 1: the LDS table holds {p, r}, so this (rare) scan reads {p, K} from global memory with wave-uniform loads
-            scan_tile<1, 0, false>(GM == 1 ? sc.sph_cull : tiles, n_pad, nullptr, c, w, sc, head, tail, lane);
+            // GM != 0: LDS holds {p, r} or nothing, so this (rare) scan reads {p, K} from global memory with wave-uniform loads
+            scan_tile<1, 0, false>(GM != 0 ? sc.sph_cull : tiles, n_pad, nullptr, c, w, sc, head, tail, lane);
         }
 
         wave_lds_sync();
@@ -639,17 +650,21 @@ int paths_blocks_per_cu(size_t dyn)
 // tables and the exact-filter mode stay on trace_kernel): ray lists with polylines out, and generator-driven renders (RENDER).
 bool paths_kernel_serves(const TraceParams& p)
 {
-    if (p.scan_mode != 0 || p.sc.n_cx != 0 || p.sc.n_sph_pad > (uint32_t)kTileSpheres || getenv("RT_HIP_NO_PATHS")) return false;
+    if (p.scan_mode != 0 || p.sc.n_cx != 0 || getenv("RT_HIP_NO_PATHS")) return false;
+    // tables beyond an LDS tile need the grid (mode 2); without one they stay on the general kernel's block-wide tiled scan
+    if (p.sc.n_sph_pad > (uint32_t)kTileSpheres && (!p.sc.grid.enabled || getenv("RT_HIP_NO_GRID"))) return false;
     if (p.rays != nullptr) return p.points != nullptr && p.n_points != nullptr;
     return p.fb_q != nullptr && p.spp != 0;  // a render launch: cell_count * spp work items
 }
 
 static bool paths_render(const TraceParams& p) { return p.rays == nullptr; }
 
-// 1: {p, r} + grid in LDS; 0: no grid (small table, or it does not fit beside the per-wave state)
+// 2: grid in global memory (tables beyond an LDS tile); 1: {p, r} + grid in LDS; 0: no grid (small table, or it does not fit beside the
+// per-wave state)
 uint32_t paths_grid_mode(const TraceParams& p)
 {
     if (!p.sc.grid.enabled || getenv("RT_HIP_NO_GRID")) return 0;
+    if (p.sc.n_sph_pad > (uint32_t)kTileSpheres) return 2;
     hipFuncAttributes fa{};
     const void* fn = paths_render(p) ? (const void*)paths_kernel<1, true> : (const void*)paths_kernel<1, false>;
     if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return 0;
@@ -659,6 +674,7 @@ uint32_t paths_grid_mode(const TraceParams& p)
 
 static size_t paths_dyn_lds(const TraceParams& p)
 {
+    if (p.grid_mode == 2) return (size_t)p.sc.n_clu * (sizeof(float4) + kClusterSize * sizeof(uint16_t));  // the clusters of the bundle cull
     return (size_t)p.sc.n_sph_pad * sizeof(float4) + (p.grid_mode == 1 ? path_grid_bytes(p.sc) : 0);
 }
 
@@ -668,8 +684,9 @@ static unsigned paths_grid(const TraceParams& p, int n_cu)
     const uint64_t items = paths_render(p) ? (uint64_t)p.cell_count * p.spp : (uint64_t)p.cell_count;
     const uint64_t want = (items + kPathThreads - 1) / kPathThreads;
     const bool r = paths_render(p);
-    const int occ = p.grid_mode == 1 ? (r ? paths_blocks_per_cu<1, true>(dyn) : paths_blocks_per_cu<1, false>(dyn))
-                                     : (r ? paths_blocks_per_cu<0, true>(dyn) : paths_blocks_per_cu<0, false>(dyn));
+    const int occ = p.grid_mode == 2   ? (r ? paths_blocks_per_cu<2, true>(dyn) : paths_blocks_per_cu<2, false>(dyn))
+                    : p.grid_mode == 1 ? (r ? paths_blocks_per_cu<1, true>(dyn) : paths_blocks_per_cu<1, false>(dyn))
+                                       : (r ? paths_blocks_per_cu<0, true>(dyn) : paths_blocks_per_cu<0, false>(dyn));
     uint64_t cap = (uint64_t)n_cu * occ;
     if (p.max_blocks && cap > p.max_blocks) cap = p.max_blocks;  // a caller whose rings hold fewer waves (the fixed workspace)
     const unsigned blocks = (unsigned)(want < cap ? want : cap);
@@ -686,8 +703,8 @@ hipError_t launch_paths(const TraceParams& p, int n_cu, int device, hipStream_t 
     static bool attr_set_dev[kMaxDevices] = {};  // function attributes are per device; callers hold the library mutex
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
     if (!attr_set_dev[device]) {
-        const void* fns[4] = {(const void*)paths_kernel<0, false>, (const void*)paths_kernel<1, false>, (const void*)paths_kernel<0, true>,
-                              (const void*)paths_kernel<1, true>};
+        const void* fns[6] = {(const void*)paths_kernel<0, false>, (const void*)paths_kernel<1, false>, (const void*)paths_kernel<2, false>,
+                              (const void*)paths_kernel<0, true>,  (const void*)paths_kernel<1, true>,  (const void*)paths_kernel<2, true>};
         for (const void* fn : fns) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPathLdsPerBlock);
             if (e != hipSuccess) return e;
@@ -697,10 +714,12 @@ hipError_t launch_paths(const TraceParams& p, int n_cu, int device, hipStream_t 
     const unsigned grid = paths_grid(p, n_cu);
     const size_t dyn = paths_dyn_lds(p);
     if (paths_render(p)) {
-        if (p.grid_mode == 1) hipLaunchKernelGGL((paths_kernel<1, true>), dim3(grid), dim3(kPathThreads), dyn, stream, p);
+        if (p.grid_mode == 2) hipLaunchKernelGGL((paths_kernel<2, true>), dim3(grid), dim3(kPathThreads), dyn, stream, p);
+        else if (p.grid_mode == 1) hipLaunchKernelGGL((paths_kernel<1, true>), dim3(grid), dim3(kPathThreads), dyn, stream, p);
         else hipLaunchKernelGGL((paths_kernel<0, true>), dim3(grid), dim3(kPathThreads), dyn, stream, p);
     } else {
-        if (p.grid_mode == 1) hipLaunchKernelGGL((paths_kernel<1, false>), dim3(grid), dim3(kPathThreads), dyn, stream, p);
+        if (p.grid_mode == 2) hipLaunchKernelGGL((paths_kernel<2, false>), dim3(grid), dim3(kPathThreads), dyn, stream, p);
+        else if (p.grid_mode == 1) hipLaunchKernelGGL((paths_kernel<1, false>), dim3(grid), dim3(kPathThreads), dyn, stream, p);
         else hipLaunchKernelGGL((paths_kernel<0, false>), dim3(grid), dim3(kPathThreads), dyn, stream, p);
     }
     return hipGetLastError();

@@ -1130,6 +1130,10 @@ def test_explicit_ray_kernel_boxes_planes_and_small_tables(engine, monkeypatch):
     small = np.array(list(random_scene(40, 1, seed=5)), dtype=abi.OBJECT_DTYPE)  # no grid: every step scans the LDS table
     _check_simulate(engine, small, _fan_rays((0, 0, -40.0), (-15.0, -8.0, -10.0), (30.0, 0, 0), (0, 16.0, 0), 32, 64), 60.0, 8, "small table", monkeypatch)
     _check_simulate(engine, small, random_rays(3000, seed=8), 60.0, 8, "small table, random rays")
+    # tables beyond an LDS tile: every ray walks the grid in global memory (GM = 2)
+    large = np.array(list(random_scene(1800, 2, seed=41, extent=(40.0, 20.0, 40.0))), dtype=abi.OBJECT_DTYPE)
+    _check_simulate(engine, large, _fan_rays((0.0, 2.0, -110.0), (-30.0, -15.0, -45.0), (60.0, 0, 0), (0, 30.0, 0), 40, 64), 120.0, 8, "large table, fan", monkeypatch)
+    _check_simulate(engine, large, random_rays(3000, seed=12, extent=(45.0, 22.0, 45.0)), 120.0, 8, "large table, random rays")
 
 
 def test_generator_renders_on_the_explicit_ray_kernel(engine, monkeypatch):
@@ -1148,7 +1152,9 @@ def test_generator_renders_on_the_explicit_ray_kernel(engine, monkeypatch):
     pg = parallel_grid((-26.0, -13.0, -60.0), (52.0, 0, 0), (0, 26.0, 0), 96, 50, (0.03, -0.02, 1.0))
     pj = projector((0.0, 1.0, -70.0), (-20.0, -10.0, -30.0), (40.0, 0, 0), (0, 20.0, 0), 80, 45)
     st = SimulationSettingsConfig(70.0, 7)
-    cases = [(big, pg, 5, 0, None, 1), (big, pg, 70, 11, 400, 3), (big, pg, 1, 96 * 50 - 1, 1, 1), (small, pg, 3, 0, None, 1), (big, pj, 4, 0, None, 1)]
+    large = np.array(list(random_scene(1500, 1, seed=43, extent=(25.0, 12.0, 25.0), r_min=0.3, r_max=1.0)), dtype=abi.OBJECT_DTYPE)  # grid in global memory
+    cases = [(big, pg, 5, 0, None, 1), (big, pg, 70, 11, 400, 3), (big, pg, 1, 96 * 50 - 1, 1, 1), (small, pg, 3, 0, None, 1), (big, pj, 4, 0, None, 1),
+             (large, pg, 3, 0, None, 1)]
     for objs, gen, spp, begin, count, step in cases:
         if gen is pj:
             monkeypatch.setenv("RT_HIP_NO_PINHOLE", "1")
