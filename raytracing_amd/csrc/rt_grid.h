@@ -139,12 +139,24 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
         bool pass[kWalkItems];
         unsigned jj[kWalkItems];
         const unsigned rem = active ? cnt - k : 0u;
+#ifndef RT_WALK_NO_PREFETCH
+        // A pass that uses its cell up (most do: a cell holds two entries on average) will step unless the walk ends, and where to
+        // does not depend on the entries: the next cell's record is read together with them, not after them.
+        const bool last = active && rem <= (unsigned)kWalkItems;
+        const float texit = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
+        const bool stepx = tmx <= tmy && tmx <= tmz, stepy = !stepx && tmy <= tmz, stepz = !stepx && !stepy;
+        const unsigned one = stepx ? 1u : (stepy ? 1u << 10 : 1u << 20);  // 1 in the stepped axis' field
+        const bool leaves = (left & (one * 0x3ffu)) == 0u;               // no cell left on that axis: the ray leaves the grid
+        const unsigned nidx = idx + (unsigned)(stepx ? ix : (stepy ? iy : iz));
+        const unsigned rec_next = cells[last && !leaves ? nidx : idx];    // idx is always a cell of the grid
+#endif
 #if RT_DBG_WALK == 6
         if (active && rem == 0u) ++dbg;  // lane-passes spent on a cell without entries (or on the start cell's record)
 #endif
 #if RT_DBG_WALK == 7
         if (lane == 0 && __ballot(rem != 0u) == 0ull) ++dbg;  // passes in which no lane tests anything
 #endif
+#ifdef RT_WALK_BRANCHY  // round 2's form: each entry under its own branches, the four reads of a pass one after the other
 #pragma unroll
         for (int u = 0; u < kWalkItems; ++u) {
             pass[u] = false;
@@ -176,13 +188,66 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
                 }
             }
         }
+#else
+        // Straight-line: the kWalkItems item reads go out together, then the kWalkItems sphere reads, then the arithmetic -- two LDS
+        // (or memory) round trips per pass instead of four.  Lanes without a u-th entry read item 0 (always there: the grid is built
+        // from 96 entries on) and drop the result; a box entry's table row is read like a sphere's and its discriminant ignored.
+        unsigned it[kWalkItems];
+#pragma unroll
+        for (int u = 0; u < kWalkItems; ++u) it[u] = items[(unsigned)u < rem ? start + k + (unsigned)u : 0u];
+        float4 s[kWalkItems];
+#pragma unroll
+        for (int u = 0; u < kWalkItems; ++u) {
+            jj[u] = it[u] & 0x7fffu;
+            s[u] = grid_sphere(sph, jj[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kWalkItems; ++u) {
+#if RT_DBG_WALK == 3
+            if ((unsigned)u < rem && !(it[u] & 0x8000u)) ++dbg;
+#endif
+            // sphere.rs:13-18, operation for operation as in sphere_first_t
+            const F3 lo = o - f3(s[u].x, s[u].y, s[u].z);
+            const float half_b = dot(lo, d);
+            const float c = dot(lo, lo) - s[u].w * s[u].w;
+            const float disc = half_b * half_b - a * c;
+            const bool box = (it[u] & 0x8000u) != 0u;  // box: the exact slab test decides
+            const bool sphere_hit = (unsigned)u < rem && !box && !(disc < 0.0f);
+            pass[u] = sphere_hit || ((unsigned)u < rem && box);
+            // tca = the parameter of closest approach.  If it is safely beyond t_min and the discriminant above the reference's 1e-6
+            // (sphere.rs:52; an absolute number, so it has to be asked for: slack scales with the scene), sphere_first_t WILL report a
+            // hit: t1 <= tca if t1 is valid, else t2 = tca + half chord <= tca + |r| / |d|, which lies beyond tca > t_min.
+            const float tca = -half_b * ia;
+            const float nb = __builtin_fminf(bound, tca + __builtin_fmaf(__builtin_fabsf(s[u].w), rs1, slack));
+            bound = (sphere_hit && tca > kTMin + slack && disc > 1e-6f) ? nb : bound;
+        }
+#endif
         k += rem < (unsigned)kWalkItems ? rem : (unsigned)kWalkItems;
 #pragma unroll
         for (int u = 0; u < kWalkItems; ++u) {
             const unsigned long long mask = __ballot(pass[u]);
             if (mask) push_candidates<R>(w, sc, mask, pass[u], slot_base, jj[u], head, tail, lane);
         }
-        // once the cell is used up: stop, or step to the next cell and read its record
+        // once the cell is used up: stop, or step to the next cell
+#ifndef RT_WALK_NO_PREFETCH
+        if (last) {
+            if (bound < texit - slack || leaves) {
+                active = false;  // everything that can still win starts before texit - slack and has been seen / the grid ends here
+            } else {
+#if RT_DBG_WALK == 5
+                ++dbg;
+#endif
+                idx = nidx;
+                tmx += stepx ? tdx : 0.0f;
+                tmy += stepy ? tdy : 0.0f;
+                tmz += stepz ? tdz : 0.0f;
+                left -= one;
+                start = rec_next & 0xfffffu;
+                cnt = rec_next >> 20;
+                k = 0;
+            }
+        }
+#else
         if (active && k >= cnt) {
             const float texit = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
             if (bound < texit - slack) {
@@ -207,6 +272,7 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
                 k = 0;
             }
         }
+#endif
     }
 }
 

@@ -699,6 +699,18 @@ def test_projector_filter_differential_fuzz():
     assert "300 cases, 0 mismatches" in r.stdout
 
 
+def test_fuzz_explicit_ray_kernel_against_general_kernel():
+    """tools/fuzz_paths.py: 300 of the same random configurations as ray lists (generator order, shuffled, parallel sheets) and as
+    ParallelGrid renders on paths_kernel and on the general kernel (RT_HIP_NO_PATHS=1) must be byte-identical."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_paths.py"), "300", "9000"], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "300 cases, 0 mismatching" in r.stdout
+
+
 @pytest.mark.parametrize("which", ["c4", "c3"])
 def test_full_resolution_c4_c3_properties(engine, which):
     """BASELINE.json configs[3] (10,000 spheres, 3840x2160) and configs[2] (100,352-triangle mesh, 1920x1080) at their full
