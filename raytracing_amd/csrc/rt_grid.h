@@ -34,6 +34,7 @@ __device__ __forceinline__ float4 grid_sphere(LdsGV4* t, unsigned j)
 }
 
 constexpr int kWalkItems = RT_WALK_ITEMS;  // entries of a cell tested per pass of the walk
+static_assert((unsigned)kWalkItems <= kGridItemPad, "the walk reads kWalkItems entries at a time, used or not");
 
 // Rays the grid may serve: the origin within the error budget (rt_host_grid.h: |o - centre| <= 2 * radius) and a finite
 // direction.  A ray with a NaN component "hits" every rotation-0 box of the scene at t_min in the reference (f32::max / min
@@ -95,12 +96,13 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
     float tmy = tdy < inf ? (g.lo[1] + (float)(cy + (sy > 0 ? 1 : 0)) * g.cell - o.y) * ivy : inf;
     float tmz = tdz < inf ? (g.lo[2] + (float)(cz + (sz > 0 ? 1 : 0)) * g.cell - o.z) * ivz : inf;
 
-    // The walk keeps its cell as one linear index and the cells left before the grid's faces as three 10-bit fields of one word:
-    // a step adds the stride of its axis and takes 1 from that axis' field (leaving the grid = stepping when the field is 0).
-    // (Three coordinates cost three selects, three range compares and two integer multiplies per step for the index.)
-    unsigned idx = ((unsigned)cz * (unsigned)dimy + (unsigned)cy) * (unsigned)dimx + (unsigned)cx;
-    const int ix = sx, iy = sy * dimx, iz = sz * dimx * dimy;
-    unsigned left = (unsigned)(sx > 0 ? dimx - 1 - cx : cx) | ((unsigned)(sy > 0 ? dimy - 1 - cy : cy) << 10) | ((unsigned)(sz > 0 ? dimz - 1 - cz : cz) << 20);
+    // The walk keeps its cell as one linear index into an array with a shell of "outside" records around the grid's cells
+    // (rt_host_grid.h): a step adds the stride of its axis, and a ray leaves the grid when the record it steps to says so -- no
+    // coordinates, no range compares, no counters.  (Round 3 first packed the cells left on each axis into one word: two selects, a
+    // mask, a compare and a subtraction per step, plus three literals the compiler re-materialised in every pass.)
+    const unsigned rowx = (unsigned)dimx + 2u, rowy = (unsigned)dimy + 2u;
+    unsigned idx = (((unsigned)cz + 1u) * rowy + (unsigned)cy + 1u) * rowx + (unsigned)cx + 1u;
+    const int ix = sx, iy = sy * (int)rowx, iz = sz * (int)(rowx * rowy);
     float bound = inf;  // upper bound of the t that will win, from spheres already queued
     unsigned k = 0, cnt = 0, start = 0;
     {
@@ -139,62 +141,26 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
         bool pass[kWalkItems];
         unsigned jj[kWalkItems];
         const unsigned rem = active ? cnt - k : 0u;
-#ifndef RT_WALK_NO_PREFETCH
         // A pass that uses its cell up (most do: a cell holds two entries on average) will step unless the walk ends, and where to
         // does not depend on the entries: the next cell's record is read together with them, not after them.
         const bool last = active && rem <= (unsigned)kWalkItems;
         const float texit = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
         const bool stepx = tmx <= tmy && tmx <= tmz, stepy = !stepx && tmy <= tmz, stepz = !stepx && !stepy;
-        const unsigned one = stepx ? 1u : (stepy ? 1u << 10 : 1u << 20);  // 1 in the stepped axis' field
-        const bool leaves = (left & (one * 0x3ffu)) == 0u;               // no cell left on that axis: the ray leaves the grid
         const unsigned nidx = idx + (unsigned)(stepx ? ix : (stepy ? iy : iz));
-        const unsigned rec_next = cells[last && !leaves ? nidx : idx];    // idx is always a cell of the grid
-#endif
+        const unsigned rec_next = cells[last ? nidx : idx];  // a walking lane sits in a cell of the grid, so nidx is at worst in the shell
 #if RT_DBG_WALK == 6
         if (active && rem == 0u) ++dbg;  // lane-passes spent on a cell without entries (or on the start cell's record)
 #endif
 #if RT_DBG_WALK == 7
         if (lane == 0 && __ballot(rem != 0u) == 0ull) ++dbg;  // passes in which no lane tests anything
 #endif
-#ifdef RT_WALK_BRANCHY  // round 2's form: each entry under its own branches, the four reads of a pass one after the other
-#pragma unroll
-        for (int u = 0; u < kWalkItems; ++u) {
-            pass[u] = false;
-            jj[u] = 0;
-            if ((unsigned)u < rem) {
-                const unsigned it = items[start + k + (unsigned)u];
-                jj[u] = it & 0x7fffu;
-                if (it & 0x8000u) {
-                    pass[u] = true;  // box: the exact slab test decides
-                } else {
-                    // sphere.rs:13-18, operation for operation as in sphere_first_t
-                    const float4 s = grid_sphere(sph, jj[u]);
-#if RT_DBG_WALK == 3
-                    ++dbg;
-#endif
-                    const F3 lo = o - f3(s.x, s.y, s.z);
-                    const float half_b = dot(lo, d);
-                    const float c = dot(lo, lo) - s.w * s.w;
-                    const float disc = half_b * half_b - a * c;
-                    if (!(disc < 0.0f)) {
-                        pass[u] = true;
-                        // tca = the parameter of closest approach.  If it is safely beyond t_min and the discriminant above the
-                        // reference's 1e-6 (sphere.rs:52; an absolute number, so it has to be asked for: slack scales with the
-                        // scene), sphere_first_t WILL report a hit: t1 <= tca if t1 is valid, else t2 = tca + half chord
-                        // <= tca + |r| / |d|, which lies beyond tca > t_min.
-                        const float tca = -half_b * ia;
-                        if (tca > kTMin + slack && disc > 1e-6f) bound = __builtin_fminf(bound, tca + __builtin_fmaf(__builtin_fabsf(s.w), rs1, slack));
-                    }
-                }
-            }
-        }
-#else
         // Straight-line: the kWalkItems item reads go out together, then the kWalkItems sphere reads, then the arithmetic -- two LDS
-        // (or memory) round trips per pass instead of four.  Lanes without a u-th entry read item 0 (always there: the grid is built
-        // from 96 entries on) and drop the result; a box entry's table row is read like a sphere's and its discriminant ignored.
+        // (or memory) round trips per pass instead of four (round 2 had each entry under its own branches: C2 -1.4 %, C4 -4 %).
+        // Lanes without a u-th entry read whatever follows in the item list (it ends with kWalkItems spare entries) and drop the
+        // result; a box entry's table row is read like a sphere's and its discriminant ignored.
         unsigned it[kWalkItems];
 #pragma unroll
-        for (int u = 0; u < kWalkItems; ++u) it[u] = items[(unsigned)u < rem ? start + k + (unsigned)u : 0u];
+        for (int u = 0; u < kWalkItems; ++u) it[u] = items[start + k + (unsigned)u];
         float4 s[kWalkItems];
 #pragma unroll
         for (int u = 0; u < kWalkItems; ++u) {
@@ -221,7 +187,6 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
             const float nb = __builtin_fminf(bound, tca + __builtin_fmaf(__builtin_fabsf(s[u].w), rs1, slack));
             bound = (sphere_hit && tca > kTMin + slack && disc > 1e-6f) ? nb : bound;
         }
-#endif
         k += rem < (unsigned)kWalkItems ? rem : (unsigned)kWalkItems;
 #pragma unroll
         for (int u = 0; u < kWalkItems; ++u) {
@@ -229,10 +194,9 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
             if (mask) push_candidates<R>(w, sc, mask, pass[u], slot_base, jj[u], head, tail, lane);
         }
         // once the cell is used up: stop, or step to the next cell
-#ifndef RT_WALK_NO_PREFETCH
         if (last) {
-            if (bound < texit - slack || leaves) {
-                active = false;  // everything that can still win starts before texit - slack and has been seen / the grid ends here
+            if (bound < texit - slack || rec_next == kGridOutside) {
+                active = false;  // everything that can still win starts before texit - slack and has been seen / the ray leaves the grid
             } else {
 #if RT_DBG_WALK == 5
                 ++dbg;
@@ -241,38 +205,11 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
                 tmx += stepx ? tdx : 0.0f;
                 tmy += stepy ? tdy : 0.0f;
                 tmz += stepz ? tdz : 0.0f;
-                left -= one;
                 start = rec_next & 0xfffffu;
                 cnt = rec_next >> 20;
                 k = 0;
             }
         }
-#else
-        if (active && k >= cnt) {
-            const float texit = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
-            if (bound < texit - slack) {
-                active = false;  // everything that can still win starts before texit - slack and has been seen
-            } else {
-#if RT_DBG_WALK == 5
-                ++dbg;
-#endif
-                const bool stepx = tmx <= tmy && tmx <= tmz, stepy = !stepx && tmy <= tmz, stepz = !stepx && !stepy;
-                const unsigned one = stepx ? 1u : (stepy ? 1u << 10 : 1u << 20);  // 1 in the stepped axis' field
-                idx += (unsigned)(stepx ? ix : (stepy ? iy : iz));
-                tmx += stepx ? tdx : 0.0f;
-                tmy += stepy ? tdy : 0.0f;
-                tmz += stepz ? tdz : 0.0f;
-                if ((left & (one * 0x3ffu)) == 0u) active = false;  // no cell left on that axis: the ray leaves the grid
-                left -= one;
-            }
-            if (active) {
-                const unsigned rec = cells[idx];
-                start = rec & 0xfffffu;
-                cnt = rec >> 20;
-                k = 0;
-            }
-        }
-#endif
     }
 }
 

@@ -119,15 +119,22 @@ inline GridHost build_grid(const std::vector<float4>& sph_exact, const std::vect
                 for (uint32_t x = x0; x <= x1; ++x) ++count[((uint64_t)z * dim[1] + y) * dim[0] + x];
     }
     if (total >= (1u << 20)) return out;
-    out.cells.resize(n_cells);
+    // The device's array has a shell of kGridOutside records around the grid's cells (rt_grid.h: a ray that steps into one has left
+    // the grid); cell (x, y, z) is at shelled(k).
+    const uint32_t rowx = dim[0] + 2, rowy = dim[1] + 2;
+    auto shelled = [&](uint64_t k) {
+        const uint64_t x = k % dim[0], y = k / dim[0] % dim[1], z = k / dim[0] / dim[1];
+        return ((z + 1) * rowy + y + 1) * rowx + x + 1;
+    };
+    out.cells.assign((size_t)rowx * rowy * (dim[2] + 2), kGridOutside);
     uint32_t run = 0;
     for (uint64_t k = 0; k < n_cells; ++k) {
-        if (count[k] > 4095) return GridHost{};
-        out.cells[k] = run | (count[k] << 20);
+        if (count[k] > 4094) return GridHost{};  // 4095 entries at offset 0xfffff would read as kGridOutside
+        out.cells[shelled(k)] = run | (count[k] << 20);
         run += count[k];
         count[k] = 0;
     }
-    out.items.resize(total ? total : 1);
+    out.items.assign(total + kGridItemPad, 0);  // the walk reads up to kGridItemPad entries past a cell's list (and drops them)
     for (uint32_t j = 0; j < n; ++j) {  // ascending j inside every cell
         uint32_t x0, x1, y0, y1, z0, z1;
         range(j, 0, x0, x1);
@@ -138,7 +145,7 @@ inline GridHost build_grid(const std::vector<float4>& sph_exact, const std::vect
             for (uint32_t y = y0; y <= y1; ++y)
                 for (uint32_t x = x0; x <= x1; ++x) {
                     const uint64_t k = ((uint64_t)z * dim[1] + y) * dim[0] + x;
-                    out.items[(out.cells[k] & 0xfffffu) + count[k]++] = item;
+                    out.items[(out.cells[shelled(k)] & 0xfffffu) + count[k]++] = item;
                 }
     }
     DevGrid& g = out.g;
@@ -154,8 +161,8 @@ inline GridHost build_grid(const std::vector<float4>& sph_exact, const std::vect
     g.radius = (float)(radius0 * 1.01);
     g.origin_r2 = (float)(4.0 * radius0 * radius0);  // |o - centre| <= 2 * radius0
     g.slack_k = 2e-3f;
-    g.n_cells = (uint32_t)n_cells;
-    g.n_items = (uint32_t)total;
+    g.n_cells = (uint32_t)out.cells.size();  // what the device holds: shell and spare entries included
+    g.n_items = (uint32_t)out.items.size();
     g.enabled = 1;
     return out;
 }

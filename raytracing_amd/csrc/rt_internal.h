@@ -56,9 +56,11 @@ constexpr uint32_t kBvhLdsNodes = 85;  // 1 + 4 + 16 + 64: the top four levels o
 
 // Uniform grid over the scan-path spheres / box bounding spheres: continuing rays of the Projector kernel
 // walk it cell by cell instead of scanning the whole table.  Built on the host when the scene is created (rt_host_grid.h).
+constexpr uint32_t kGridOutside = 0xffffffffu;  // record of the shell around the grid's cells: a ray that steps into it has left the grid
+constexpr uint32_t kGridItemPad = 4;            // spare entries behind the item list (>= the entries a walk pass reads at once)
 struct DevGrid {
-    const uint32_t* cells;   // [dim x * dim y * dim z] first item (bits 0..19) | item count (bits 20..31); x fastest
-    const uint16_t* items;   // sphere index j (bits 0..14) | bit 15: entry j is a box (no discriminant pre-test)
+    const uint32_t* cells;   // [(dim x + 2) * (dim y + 2) * (dim z + 2)] first item (bits 0..19) | item count (bits 20..31); x fastest; the outermost layer is kGridOutside
+    const uint16_t* items;   // sphere index j (bits 0..14) | bit 15: entry j is a box (no discriminant pre-test); kGridItemPad spare entries at the end
     float lo[3], hi[3];      // bounds of the grid (contain every registered, inflated sphere box)
     float cell, inv_cell;    // cubic cells
     uint32_t dim[3];
@@ -66,7 +68,7 @@ struct DevGrid {
     float radius;            // half diagonal of the bounds
     float origin_r2;         // rays whose origin lies farther than sqrt(origin_r2) from `centre` take the table scan instead
     float slack_k;           // t slack of a ray = slack_k * (|o - centre| + radius) / |d|
-    uint32_t n_cells, n_items;
+    uint32_t n_cells, n_items;  // array lengths, shell and spare entries included
     uint32_t enabled;        // 0: no grid for this scene (few spheres, non-finite data, oversized lists)
 };
 
