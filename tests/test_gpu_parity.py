@@ -1148,6 +1148,61 @@ def test_explicit_ray_kernel_boxes_planes_and_small_tables(engine, monkeypatch):
     _check_simulate(engine, large, random_rays(3000, seed=12, extent=(45.0, 22.0, 45.0)), 120.0, 8, "large table, random rays")
 
 
+@pytest.mark.parametrize("shape", ["sheet", "line", "lattice", "sheet_large"])
+def test_thin_and_flat_grids_against_the_oracle(engine, monkeypatch, shape):
+    """Grids one cell thick (sphere centres in a plane), one cell wide in two axes (centres on a line) and a lattice whose spheres
+    sit on cell boundaries: the shell of "outside" records around the cells (rt_grid.h) is then most of the array.  Random rays,
+    axis-parallel rays (no boundary crossings on two axes), rays inside the sheet's plane and rays that touch the grid's faces;
+    ray lists on both kernels and a Projector render, LDS-resident and global-memory grids."""
+    rng = np.random.default_rng({"sheet": 1, "line": 2, "lattice": 3, "sheet_large": 4}[shape])
+    kinds = (abi.RT_MAT_GLASS, abi.RT_MAT_MIRROR, abi.RT_MAT_HALF_MIRROR)
+    if shape in ("sheet", "sheet_large"):
+        side = 20 if shape == "sheet" else 40
+        ctr = np.array([(2.5 * i + rng.uniform(-0.4, 0.4), 0.0, 2.5 * j + rng.uniform(-0.4, 0.4)) for i in range(side) for j in range(side)])
+        ctr -= ctr.mean(0)
+        rad = rng.uniform(0.5, 1.0, len(ctr))
+    elif shape == "line":
+        ctr = np.array([(0.0, 0.0, 2.2 * k) for k in range(300)]) - np.array([0.0, 0.0, 330.0])
+        rad = rng.uniform(0.6, 1.0, len(ctr))
+    else:
+        ctr = np.array([(3.0 * i, 3.0 * j, 3.0 * k) for i in range(8) for j in range(8) for k in range(8)], dtype=np.float64) - 10.5
+        rad = np.full(len(ctr), 1.2)
+    objs = np.array([sphere(ctr[k], rad[k], kinds[k % 3], (1.5, 0.0, 0.5)[k % 3]) for k in range(len(ctr))], dtype=abi.OBJECT_DTYPE)
+    ext = np.abs(ctr).max(0) + 3.0
+    n = 1500
+    o = (rng.uniform(-1.3, 1.3, (n, 3)) * ext).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    axis = np.zeros((600, 3), np.float32)  # axis-parallel rays, both senses, from outside and from between the spheres
+    axis[np.arange(600), np.arange(600) % 3] = np.where(np.arange(600) % 2, 1.0, -1.0)
+    ao = (rng.uniform(-1.1, 1.1, (600, 3)) * ext).astype(np.float32)
+    inplane = rng.standard_normal((400, 3)).astype(np.float32)  # in the plane y = 0 of the sheet / through the line's axis
+    inplane[:, 1] = 0.0
+    io = (rng.uniform(-1.2, 1.2, (400, 3)) * ext).astype(np.float32)
+    io[:, 1] = 0.0
+    lo, hi = (ctr - rad[:, None]).min(0), (ctr + rad[:, None]).max(0)  # rays along the faces of the spheres' bounding box
+    fo = np.array([(lo[0] if k % 2 else hi[0], rng.uniform(lo[1], hi[1]), lo[2] - 5.0) for k in range(100)], np.float32)
+    fd = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (100, 1))
+    rays = make_rays(np.concatenate([o, ao, io, fo]), np.concatenate([d, axis, inplane, fd]))
+    inf_dist = float(4.0 * np.linalg.norm(ext))
+    npts = _check_simulate(engine, objs, rays, inf_dist, 8, shape, monkeypatch)
+    assert (npts > 2).sum() > 150, shape
+    # the Projector kernel's continuing rays on the same grid
+    st = SimulationSettingsConfig(inf_dist, 6)
+    eye = np.array([0.3 * ext[0], 2.5 * ext[1] + 20.0, -1.6 * ext[2]])
+    fwd = -eye / np.linalg.norm(eye)
+    right = np.cross(fwd, [0.0, 1.0, 0.0])
+    right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+    dist = np.linalg.norm(eye)
+    w_, h_ = 0.9 * dist, 0.6 * dist
+    gen = projector(eye, eye + fwd * dist - 0.5 * w_ * right - 0.5 * h_ * up, w_ * right, h_ * up, 48, 40)
+    got = engine.Scene(objs).render(gen, 3, st, seed=11)
+    want = ob.OracleScene(objs).render(gen, 3, st.infinity_distance, st.max_bounces, seed=11, threads=8)
+    for a, b in zip(got[:4], want[:4]):
+        assert same(a, b), shape
+    assert got[4] == want[4] and (got[1] >= 0).mean() > (0.002 if shape == "line" else 0.1), shape
+
+
 def test_generator_renders_on_the_explicit_ray_kernel(engine, monkeypatch):
     """ParallelGrid renders (and Projector renders the Projector kernel declines: RT_HIP_NO_PINHOLE) run on paths_kernel<GM, RENDER = true>:
     framebuffer, first-hit ids / t, per-cell segment counts and the segment total against the oracle, and the same bytes from the general
