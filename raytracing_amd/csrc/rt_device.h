@@ -190,6 +190,9 @@ __device__ __forceinline__ void confirm_batch(WaveLds<R>& w, const DevScene& sc,
 // entry and takes no part in the scan (confirm_batch still runs the exact test on it).
 __device__ __forceinline__ bool nan_ray(F3 d) { return d.x != d.x && d.y != d.y && d.z != d.z; }
 template <int R>
+__device__ __forceinline__ void push_candidates(WaveLds<R>& w, const DevScene& sc, unsigned long long mask, bool mine, unsigned slot_base,
+                                                unsigned j, unsigned& head, unsigned& tail, unsigned lane);
+template <int R>
 __device__ __forceinline__ void push_nan_rays(WaveLds<R>& w, const DevScene& sc, bool is_nan, unsigned slot_base, unsigned& head, unsigned& tail,
                                               unsigned lane)
 {
