@@ -85,14 +85,29 @@ static void fuzz_grids()
         if (n && it % 19 == 0) ex[rnd(n)].w = span * 40.0f;  // one giant among the small: long item lists
         if (n && it % 23 == 0) for (uint32_t j = 0; j < n; ++j) ex[j] = ex[0];  // all coincident
         const rt::host::GridHost g = rt::host::build_grid(ex, bx, n);
-        if (g.g.enabled) {  // every cell's item range must lie inside the item array
-            for (uint32_t c : g.cells) {
-                const uint32_t first = c & 0xfffffu, cnt = c >> 20;
-                if ((size_t)first + cnt > g.items.size()) {
-                    std::fprintf(stderr, "grid cell range out of bounds\n");
-                    std::abort();
-                }
+        if (g.g.enabled) {
+            // the array the device walks: (dim + 2)^3 records, the outermost layer "outside", every other cell's item range -- plus the
+            // spare entries a walk pass reads past it -- inside the item array
+            const uint32_t rx = g.g.dim[0] + 2, ry = g.g.dim[1] + 2, rz = g.g.dim[2] + 2;
+            if (g.cells.size() != (size_t)rx * ry * rz || g.g.n_cells != g.cells.size() || g.g.n_items != g.items.size()) {
+                std::fprintf(stderr, "grid array sizes do not match the dimensions\n");
+                std::abort();
             }
+            for (uint32_t z = 0; z < rz; ++z)
+                for (uint32_t y = 0; y < ry; ++y)
+                    for (uint32_t x = 0; x < rx; ++x) {
+                        const uint32_t c = g.cells[((size_t)z * ry + y) * rx + x];
+                        const bool shell = x == 0 || y == 0 || z == 0 || x == rx - 1 || y == ry - 1 || z == rz - 1;
+                        if (shell != (c == rt::kGridOutside)) {
+                            std::fprintf(stderr, "grid shell record misplaced\n");
+                            std::abort();
+                        }
+                        const uint32_t first = c & 0xfffffu, cnt = c >> 20;
+                        if (!shell && (size_t)first + cnt + rt::kGridItemPad > g.items.size()) {
+                            std::fprintf(stderr, "grid cell range out of bounds\n");
+                            std::abort();
+                        }
+                    }
             for (uint16_t i : g.items)
                 if ((uint32_t)(i & 0x7fffu) >= n) {
                     std::fprintf(stderr, "grid item index out of range\n");
