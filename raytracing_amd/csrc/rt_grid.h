@@ -13,6 +13,8 @@
 //     the ray up to bound + slack every entry that could still win has been seen.
 // Control flow is wave-uniform (the loop runs while any lane is walking), so the candidate queue works as in the table scan.
 #pragma once
+#include <type_traits>
+
 #include "rt_device.h"
 
 #ifndef RT_WALK_ITEMS
@@ -45,11 +47,17 @@ __device__ __forceinline__ bool grid_admits(const DevGrid& g, F3 o, F3 d)
     return dot(oc, oc) <= g.origin_r2 && dot(d, d) < __builtin_inff();
 }
 
-template <int R, typename CellPtr, typename ItemPtr, typename SphPtr>
+template <int R, bool ASK = true, typename CellPtr, typename ItemPtr, typename SphPtr>
 __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemPtr items, SphPtr sph, F3 o, F3 d, float a, bool live,
                                           unsigned slot_base, WaveLds<R>& w, const DevScene& sc, unsigned& head, unsigned& tail, unsigned lane,
                                           unsigned long long& dbg)
 {
+    // Reads that may turn out unused (entries a lane does not have, the next cell's record of a lane that stays) are made by every lane
+    // without a branch when the grid is in LDS.  With the grid in global memory the caller chooses: ASK = true reads per lane and only what
+    // exists -- for rays that walk in from outside through empty cells (ray lists: the 10,000-sphere list 2.12 -> 1.51 ms); ASK = false
+    // reads unconditionally as in LDS -- for the Projector kernel's continuing rays, which start on surfaces inside the cloud (C4 at
+    // 128 spp: 36.9 against 37.7 ms).
+    constexpr bool kUnconditional = !std::is_same<CellPtr, const uint32_t*>::value || !ASK;
     const float inf = __builtin_inff();
     const float rs = __builtin_amdgcn_rsqf(a);  // ~ 1 / |d|
     const F3 oc = o - f3(g.centre[0], g.centre[1], g.centre[2]);
@@ -147,7 +155,10 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
         const float texit = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
         const bool stepx = tmx <= tmy && tmx <= tmz, stepy = !stepx && tmy <= tmz, stepz = !stepx && !stepy;
         const unsigned nidx = idx + (unsigned)(stepx ? ix : (stepy ? iy : iz));
-        const unsigned rec_next = cells[last ? nidx : idx];  // a walking lane sits in a cell of the grid, so nidx is at worst in the shell
+        // (a walking lane sits in a cell of the grid, so nidx is at worst in the shell)
+        unsigned rec_next = 0u;
+        if constexpr (kUnconditional) rec_next = cells[last ? nidx : idx];  // every lane reads, no branch
+        else if (last) rec_next = cells[nidx];                              // only the lanes that need it ask
 #if RT_DBG_WALK == 6
         if (active && rem == 0u) ++dbg;  // lane-passes spent on a cell without entries (or on the start cell's record)
 #endif
@@ -158,14 +169,30 @@ __device__ __forceinline__ void grid_walk(const DevGrid& g, CellPtr cells, ItemP
         // (or memory) round trips per pass instead of four (round 2 had each entry under its own branches: C2 -1.4 %, C4 -4 %).
         // Lanes without a u-th entry read whatever follows in the item list (it ends with kWalkItems spare entries) and drop the
         // result; a box entry's table row is read like a sphere's and its discriminant ignored.
+        // With the grid in global memory the reads are per lane and only for entries that exist: a ray that walks in from outside through
+        // empty cells would otherwise wait for gathers it drops (the 10,000-sphere ray list: 1.6 -> 2.15 ms with unconditional reads).
         unsigned it[kWalkItems];
-#pragma unroll
-        for (int u = 0; u < kWalkItems; ++u) it[u] = items[start + k + (unsigned)u];
         float4 s[kWalkItems];
+        if constexpr (kUnconditional) {
 #pragma unroll
-        for (int u = 0; u < kWalkItems; ++u) {
-            jj[u] = it[u] & 0x7fffu;
-            s[u] = grid_sphere(sph, jj[u]);
+            for (int u = 0; u < kWalkItems; ++u) it[u] = items[start + k + (unsigned)u];
+#pragma unroll
+            for (int u = 0; u < kWalkItems; ++u) {
+                jj[u] = it[u] & 0x7fffu;
+                s[u] = grid_sphere(sph, jj[u]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kWalkItems; ++u) {
+                it[u] = 0u;
+                if ((unsigned)u < rem) it[u] = items[start + k + (unsigned)u];
+            }
+#pragma unroll
+            for (int u = 0; u < kWalkItems; ++u) {
+                jj[u] = it[u] & 0x7fffu;
+                s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((unsigned)u < rem) s[u] = grid_sphere(sph, jj[u]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < kWalkItems; ++u) {

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
                 for (int r = 0; r < R; ++r) {
                     const float a = dot(rd[r], rd[r]);
                     if constexpr (STREAM)  // grid mode 2
-                        grid_walk<R>(gw, gw.cells, gw.items, sc.sph_exact, ro[r], rd[r], a, scan_live[r], r * 64u, w, sc, head, tail, lane, my_dbg);
+                        grid_walk<R, false>(gw, gw.cells, gw.items, sc.sph_exact, ro[r], rd[r], a, scan_live[r], r * 64u, w, sc, head, tail, lane, my_dbg);
                     else  // grid mode 1
                         grid_walk<R>(gw, (LdsU32*)grid_lds, (LdsU16*)(grid_lds + gw.n_cells), (LdsGV4*)tiles, ro[r], rd[r], a, scan_live[r], r * 64u, w, sc,
                                      head, tail, lane, my_dbg);
