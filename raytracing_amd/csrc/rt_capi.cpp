@@ -327,6 +327,9 @@ int enqueue(rt::TraceParams& p, unsigned long long* d_total, hipStream_t stream,
     } else {
         HIP_TRY(rt::launch_trace(p, g_ctx.n_cu, g_ctx.device, stream));
     }
+    if (getenv("RT_HIP_TRACE_DISPATCH"))  // which kernel served the call and where its grid lives (tests of the dispatch rules read this)
+        std::fprintf(stderr, "rt_hip dispatch: %s grid_mode %u entries %u grid %u\n",
+                     pinhole ? "pinhole_kernel" : (rt::paths_kernel_serves(p) ? "paths_kernel" : "trace_kernel"), p.grid_mode, p.sc.n_sph, p.sc.grid.enabled);
     return RT_OK;
 }
 
@@ -586,13 +589,16 @@ int rt_hip_scene_create_desc(const RtSceneDesc* desc, rt_scene** out_scene)
     const uint32_t pad_to = n_sph > (uint32_t)rt::kTileSpheres ? 64u : (uint32_t)rt::kUnroll;
     const uint32_t n_pad = (n_sph + pad_to - 1) / pad_to * pad_to;
     const float inf = std::numeric_limits<float>::infinity();
-    for (uint32_t k = n_sph; k < n_pad; ++k) {
+    // The arrays themselves end on a 64-entry boundary whatever n_pad is: a table of the LDS size class whose grid does not fit into
+    // LDS runs on the streamed kernels (grid_mode 2), and their scans read whole 64-sphere rows.
+    const uint32_t n_alloc = (n_pad + 63u) / 64u * 64u;
+    for (uint32_t k = n_sph; k < n_alloc; ++k) {
         sph_cull.push_back(make_float4(0, 0, 0, inf));  // never passes the filter
         sph_exact.push_back(make_float4(0, 0, 0, 1));
         sph_box.push_back(make_float4(0, 0, 0, 0));
         sph_obj.push_back(-1);
     }
-    std::vector<uint2> sph_mat(n_pad, make_uint2(0, 0));
+    std::vector<uint2> sph_mat(n_alloc, make_uint2(0, 0));
     uint32_t n_box = 0, first_box = 0;
     for (uint32_t k = 0; k < n_sph; ++k) {
         sph_mat[k] = obj_mat[sph_obj[k]];

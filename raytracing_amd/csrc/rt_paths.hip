@@ -659,8 +659,8 @@ bool paths_kernel_serves(const TraceParams& p)
 
 static bool paths_render(const TraceParams& p) { return p.rays == nullptr; }
 
-// 2: grid in global memory (tables beyond an LDS tile); 1: {p, r} + grid in LDS; 0: no grid (small table, or it does not fit beside the
-// per-wave state)
+// 2: grid in global memory (tables beyond an LDS tile, and grids that do not fit into LDS beside the table and the per-wave state);
+// 1: {p, r} + grid in LDS; 0: no grid (small table)
 uint32_t paths_grid_mode(const TraceParams& p)
 {
     if (!p.sc.grid.enabled || getenv("RT_HIP_NO_GRID")) return 0;
@@ -669,7 +669,7 @@ uint32_t paths_grid_mode(const TraceParams& p)
     const void* fn = paths_render(p) ? (const void*)paths_kernel<1, true> : (const void*)paths_kernel<1, false>;
     if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return 0;
     const size_t need = fa.sharedSizeBytes + (size_t)p.sc.n_sph_pad * sizeof(float4) + path_grid_bytes(p.sc) + 512;
-    return need <= kPathLdsPerBlock ? 1u : 0u;
+    return need <= kPathLdsPerBlock && !getenv("RT_HIP_GRID_IN_MEMORY") ? 1u : 2u;  // long item lists: the grid stays in global memory
 }
 
 static size_t paths_dyn_lds(const TraceParams& p)

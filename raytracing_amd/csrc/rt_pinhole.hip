@@ -610,7 +610,9 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
 #endif
 constexpr int kR = RT_PIN_R;
 
-inline bool stream_mode(const TraceParams& p) { return p.sc.n_sph_pad > (uint32_t)kTileSpheres; }
+// The streamed kernel (tables and grid read from global memory) serves tables beyond an LDS tile, and smaller ones whose grid does not fit
+// into LDS beside the table and the per-wave state (grid_mode 2: long item lists -- large radii, grids of boxes).
+inline bool stream_mode(const TraceParams& p) { return p.sc.n_sph_pad > (uint32_t)kTileSpheres || p.grid_mode == 2; }
 constexpr size_t kLdsPerBlock = 80 * 1024;  // two 512-thread blocks per CU share 160 KB
 inline size_t grid_lds_bytes(const DevGrid& g) { return ((size_t)g.n_cells * 4 + ((size_t)g.n_items + 1) / 2 * 4 + 15) / 16 * 16; }
 // 0: no grid; 1: LDS-table kernel with {p, r}, cells and items in LDS; 2: streamed kernel, grid read from global memory
@@ -619,7 +621,7 @@ inline uint32_t grid_mode_of(const TraceParams& p, size_t static_lds)
     if (!p.sc.grid.enabled || getenv("RT_HIP_NO_GRID")) return 0;
     if (stream_mode(p)) return 2;
     const size_t need = static_lds + (size_t)p.sc.n_sph_pad * sizeof(float4) + grid_lds_bytes(p.sc.grid) + 512;
-    return need <= kLdsPerBlock ? 1 : 0;
+    return need <= kLdsPerBlock && !getenv("RT_HIP_GRID_IN_MEMORY") ? 1 : 2;  // (the environment switch: tests of the fallback)
 }
 inline size_t table_lds(const TraceParams& p)
 {

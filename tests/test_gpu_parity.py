@@ -1203,6 +1203,39 @@ def test_thin_and_flat_grids_against_the_oracle(engine, monkeypatch, shape):
     assert got[4] == want[4] and (got[1] >= 0).mean() > (0.002 if shape == "line" else 0.1), shape
 
 
+@pytest.mark.parametrize("how", ["fat", "forced", "forced_odd"])
+def test_grids_that_do_not_fit_into_lds_are_walked_in_memory(engine, monkeypatch, capfd, how):
+    """A table of the LDS size class whose grid does not fit into LDS beside it (item lists of fat, overlapping spheres; or any scene with
+    RT_HIP_GRID_IN_MEMORY=1) keeps the grid in global memory: the Projector render runs on the streamed kernel (whose scans read whole
+    64-sphere rows: the sphere count of "forced_odd" is not a multiple of 64 or 4) and ray lists on paths_kernel<2>."""
+    rng = np.random.default_rng(77)
+    kinds = (abi.RT_MAT_GLASS, abi.RT_MAT_MIRROR, abi.RT_MAT_HALF_MIRROR)
+    if how == "fat":
+        n = 1000  # 10 x 10 x 10 lattice, spacing 3, radii up to 3: a sphere is registered in a dozen cells on average
+        ctr = np.array([(3.0 * i, 3.0 * j, 3.0 * k) for i in range(10) for j in range(10) for k in range(10)], np.float64) - 13.5 + rng.uniform(-0.3, 0.3, (1000, 3))
+        rad = rng.uniform(0.3, 3.0, n)
+        objs = np.array([sphere(ctr[k], rad[k], kinds[k % 3], (1.5, 0.0, 0.5)[k % 3]) for k in range(n)], dtype=abi.OBJECT_DTYPE)
+    else:
+        monkeypatch.setenv("RT_HIP_GRID_IN_MEMORY", "1")
+        objs = np.array(list(random_scene(401 if how == "forced_odd" else 640, 2, seed=23, extent=(25.0, 12.0, 25.0))), dtype=abi.OBJECT_DTYPE)
+    st = SimulationSettingsConfig(150.0, 7)
+    gen = projector((1.0, 3.0, -70.0), (-24.0, -14.0, -20.0), (50.0, 0.0, 0.0), (0.0, 32.0, 0.0), 56, 40)
+    monkeypatch.setenv("RT_HIP_TRACE_DISPATCH", "1")
+    capfd.readouterr()
+    got = engine.Scene(objs).render(gen, 5, st, seed=3)
+    assert "pinhole_kernel grid_mode 2" in capfd.readouterr().err, how
+    want = ob.OracleScene(objs).render(gen, 5, st.infinity_distance, st.max_bounces, seed=3, threads=8)
+    for a, b in zip(got[:4], want[:4]):
+        assert same(a, b), how
+    assert got[4] == want[4] and (got[1] >= 0).mean() > 0.3, how
+    fan = _fan_rays((0.0, 1.0, -70.0), (-20.0, -10.0, -30.0), (40.0, 0, 0), (0, 20.0, 0), 40, 64)
+    npts = _check_simulate(engine, objs, fan, 150.0, 7, how, monkeypatch)
+    err = capfd.readouterr().err
+    assert "paths_kernel grid_mode 2" in err and "trace_kernel" in err, how  # (the second call of the check: the general kernel)
+    assert (npts > 2).sum() > 500, how
+    _check_simulate(engine, objs, random_rays(3000, seed=5, extent=(30.0, 15.0, 30.0)), 150.0, 7, how + ", random rays")
+
+
 def test_generator_renders_on_the_explicit_ray_kernel(engine, monkeypatch):
     """ParallelGrid renders (and Projector renders the Projector kernel declines: RT_HIP_NO_PINHOLE) run on paths_kernel<GM, RENDER = true>:
     framebuffer, first-hit ids / t, per-cell segment counts and the segment total against the oracle, and the same bytes from the general
