@@ -711,6 +711,21 @@ def test_fuzz_explicit_ray_kernel_against_general_kernel():
     assert "300 cases, 0 mismatching" in r.stdout
 
 
+@pytest.mark.parametrize("in_memory", [False, True])
+def test_fuzz_renders_against_the_oracle(in_memory):
+    """tests/fuzz_oracle.py: 500 of the random projector / sphere-cloud configurations rendered on the GPU and by the CPU oracle, with
+    the grid where the library puts it and forced into global memory (15,000 cases ran clean when this was written)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **({"RT_HIP_GRID_IN_MEMORY": "1"} if in_memory else {}))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_oracle.py"), "500", "11000" if in_memory else "12000"], capture_output=True, text=True,
+                       timeout=280, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "500 cases, 0 mismatching" in r.stdout
+
+
 @pytest.mark.parametrize("which", ["c4", "c3"])
 def test_full_resolution_c4_c3_properties(engine, which):
     """BASELINE.json configs[3] (10,000 spheres, 3840x2160) and configs[2] (100,352-triangle mesh, 1920x1080) at their full
