@@ -156,6 +156,10 @@ def valu_roofline(pmc, stale, rates, render_ms, launches, share, segs_local, ker
         "valu_issue_util": issue,
         "valu_lane_util": lane,
         "useful_lane_fraction": None if issue is None or lane is None else issue * lane,
+        "lane_util_note": "valu_lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): lanes ENABLED in the exec mask, not lanes with "
+                          "work.  The grid walk's pass is straight-line code since late round 3 (entries a lane does not have are computed and "
+                          "dropped), so this reads higher than the share of lanes doing useful work; the walk's own occupancy (lanes still "
+                          "walking per pass, -DRT_DBG_WALK counters) is 0.61 on C2 (DESIGN.md 4.2b, 4.8)",
         "pmc_source": None if stale else pmc.get("source"),
         "pmc_stale": stale,
         "hbm": None if traffic is None else {"achieved": traffic * share / sec / 1e9, "peak": 8000.0, "unit": "GB/s",
