@@ -261,10 +261,18 @@ __device__ __forceinline__ void bvh_order(float& ta, uint32_t& ca, float& tb, ui
 typedef float V4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const V4f LdsF4;
 __device__ __forceinline__ float4 lds_f4(LdsF4* q) { const V4f v = *q; return make_float4(v.x, v.y, v.z, v.w); }
+typedef unsigned V2u __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) V2u LdsU2;
 struct BvhLds {
     LdsF4* nodes;
     uint32_t count;
+    LdsU2* stack;  // this lane's column of the block's short traversal stack: entry k at stack[k * kBvhLdsStackStride] (nullptr: none)
 };
+#ifndef RT_BVH_LDS_STACK
+#define RT_BVH_LDS_STACK 6  // entries of the traversal stack that live in LDS (the bottom ones; deeper entries go to private memory)
+#endif
+constexpr unsigned kBvhLdsStack = RT_BVH_LDS_STACK;
+constexpr unsigned kBvhLdsStackStride = 512;  // threads of the block that owns the array
 
 // mesh_first_hit is inlined into its two callers, cx_first_hit stays a call (measured on C3, 256 spp: both calls 110.5 ms, the
 // traversal inlined 108.6 ms, both inlined 117.0 ms: the kernel runs at the 128-VGPR cap and what is live across a call spills)
@@ -290,10 +298,32 @@ __device__ RT_MESH_INLINE bool mesh_first_hit(const DevScene& sc, BvhLds top, ui
     GlbF4* const g_tris = (GlbF4*)sc.tris;        // 3 per triangle: v0, e1, e2
     auto glb_f4 = [](GlbF4* q) { const V4f v = *q; return make_float4(v.x, v.y, v.z, v.w); };
     auto load_tri = [&](uint32_t k) { TriDev t; t.v0 = glb_f4(g_tris + 3u * k); t.e1 = glb_f4(g_tris + 3u * k + 1u); t.e2 = glb_f4(g_tris + 3u * k + 2u); return t; };
+    // The traversal stack: the first kBvhLdsStack entries in the block's LDS (most pushes and pops happen there: a 4-wide tree over 10^5
+    // triangles is nine levels deep), the rest in private memory.  All in private memory it was most of the 2.4 TB/s the C3 frame moved.
+    constexpr uint32_t kDone = 0x7fffffffu;  // not a node index (node counts stay far below 2^31)
     uint32_t stack[kBvhStack];
     float stack_t[kBvhStack];
     int sp = 0;
-    constexpr uint32_t kDone = 0x7fffffffu;  // not a node index (node counts stay far below 2^31)
+    const int n_lds = top.stack ? (int)kBvhLdsStack : 0;
+    auto push = [&](uint32_t c, float t) {
+        if (sp < kBvhStack) {
+            if (sp < n_lds) top.stack[sp * kBvhLdsStackStride] = V2u{c, __float_as_uint(t)};
+            else { stack[sp - n_lds] = c; stack_t[sp - n_lds] = t; }
+            ++sp;
+        }
+    };
+    // pop, skipping entries the best hit found since has put out of reach
+    auto pop = [&](float best_now) {
+        while (sp > 0) {
+            --sp;
+            uint32_t c;
+            float t;
+            if (sp < n_lds) { const V2u e = top.stack[sp * kBvhLdsStackStride]; c = e.x; t = __uint_as_float(e.y); }
+            else { c = stack[sp - n_lds]; t = stack_t[sp - n_lds]; }
+            if (t <= best_now) return c;
+        }
+        return kDone;
+    };
     uint32_t cur = root;
     // "while-while": every lane first descends to its next leaf, then the wave tests leaves together, so the expensive
     // triangle code runs with as many lanes as possible
@@ -324,21 +354,10 @@ __device__ RT_MESH_INLINE bool mesh_first_hit(const DevScene& sc, BvhLds top, ui
             bvh_order(t0, c0, t2, c2);
             bvh_order(t1, c1, t3, c3);
             bvh_order(t1, c1, t2, c2);
-            if (t3 < inf && sp < kBvhStack) { stack[sp] = c3; stack_t[sp] = t3; ++sp; }
-            if (t2 < inf && sp < kBvhStack) { stack[sp] = c2; stack_t[sp] = t2; ++sp; }
-            if (t1 < inf && sp < kBvhStack) { stack[sp] = c1; stack_t[sp] = t1; ++sp; }
-            if (t0 < inf) {
-                cur = c0;
-            } else {
-                cur = kDone;  // pop, skipping entries the best hit found since has put out of reach
-                while (sp > 0) {
-                    --sp;
-                    if (stack_t[sp] <= best) {
-                        cur = stack[sp];
-                        break;
-                    }
-                }
-            }
+            if (t3 < inf) push(c3, t3);
+            if (t2 < inf) push(c2, t2);
+            if (t1 < inf) push(c1, t1);
+            cur = t0 < inf ? c0 : pop(best);
         }
         if (cur == kDone) break;
         const uint32_t first = (cur & 0x7fffffffu) >> 3, cnt = cur & 7u;
@@ -366,14 +385,7 @@ __device__ RT_MESH_INLINE bool mesh_first_hit(const DevScene& sc, BvhLds top, ui
                 best_k = k;
             }
         }
-        cur = kDone;
-        while (sp > 0) {
-            --sp;
-            if (stack_t[sp] <= best) {
-                cur = stack[sp];
-                break;
-            }
-        }
+        cur = pop(best);
     }
     if (best_id == 0xffffffffu) return false;
     const TriDev tr = load_tri(best_k);

@@ -1,5 +1,5 @@
 """Frame time of the Projector render path on one GPU (HIP events around rt_hip_render_dev), for quick A/B runs.
-usage: time_frame.py [c2|c4] [width height spp depth reps cell_step]   (cell_step N: rank 0's share of a frame dealt round-robin to N ranks)   (RT_HIP_NO_GRID=1 etc. are read by the library)"""
+usage: time_frame.py [c2|c3|c4] [width height spp depth reps cell_step]   (cell_step N: rank 0's share of a frame dealt round-robin to N ranks)   (RT_HIP_NO_GRID=1 etc. are read by the library)"""
 import os
 import sys
 
@@ -11,16 +11,16 @@ from raytracing_amd import engine, sharding, synth
 from raytracing_amd.engine import SimulationSettingsConfig
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c2"
-make = {"c2": synth.config_c2, "c4": synth.config_c4}[name]
-w = int(sys.argv[2]) if len(sys.argv) > 2 else (1920 if name == "c2" else 3840)
-h = int(sys.argv[3]) if len(sys.argv) > 3 else (1080 if name == "c2" else 2160)
+make = {"c2": synth.config_c2, "c3": synth.config_c3, "c4": synth.config_c4}[name]
+w = int(sys.argv[2]) if len(sys.argv) > 2 else (3840 if name == "c4" else 1920)
+h = int(sys.argv[3]) if len(sys.argv) > 3 else (2160 if name == "c4" else 1080)
 cfg = make(w, h)
 spp = int(sys.argv[4]) if len(sys.argv) > 4 else cfg["spp"]
 depth = int(sys.argv[5]) if len(sys.argv) > 5 else cfg["max_bounces"]
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 10
 step = int(sys.argv[7]) if len(sys.argv) > 7 else 1
 engine.init(0)
-sc = engine.Scene(cfg["objects"])
+sc = engine.Scene(cfg["objects"], meshes=cfg.get("meshes"))
 st = SimulationSettingsConfig(cfg["infinity_distance"], depth)
 n = (w * h + step - 1) // step
 fb = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
