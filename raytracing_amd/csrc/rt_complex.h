@@ -266,12 +266,17 @@ typedef __attribute__((address_space(3))) V2u LdsU2;
 struct BvhLds {
     LdsF4* nodes;
     uint32_t count;
-    LdsU2* stack;  // this lane's column of the block's short traversal stack: entry k at stack[k * kBvhLdsStackStride] (nullptr: none)
+    LdsU2* stack;     // this lane's column of the block's short traversal stack: entry k at stack[k * kBvhLdsStackStride] (nullptr: none)
+    uint32_t n_stack;  // its entries
 };
 #ifndef RT_BVH_LDS_STACK
 #define RT_BVH_LDS_STACK 6  // entries of the traversal stack that live in LDS (the bottom ones; deeper entries go to private memory)
 #endif
+#ifndef RT_BVH_LDS_STACK_STREAM
+#define RT_BVH_LDS_STACK_STREAM 3  // the streamed kernel's static LDS is 16 KB larger: a shorter one keeps two blocks per CU
+#endif
 constexpr unsigned kBvhLdsStack = RT_BVH_LDS_STACK;
+constexpr unsigned kBvhLdsStackStream = RT_BVH_LDS_STACK_STREAM;
 constexpr unsigned kBvhLdsStackStride = 512;  // threads of the block that owns the array
 
 // mesh_first_hit is inlined into its two callers, cx_first_hit stays a call (measured on C3, 256 spp: both calls 110.5 ms, the
@@ -304,7 +309,7 @@ __device__ RT_MESH_INLINE bool mesh_first_hit(const DevScene& sc, BvhLds top, ui
     uint32_t stack[kBvhStack];
     float stack_t[kBvhStack];
     int sp = 0;
-    const int n_lds = top.stack ? (int)kBvhLdsStack : 0;
+    const int n_lds = top.stack ? (int)top.n_stack : 0;
     auto push = [&](uint32_t c, float t) {
         if (sp < kBvhStack) {
             if (sp < n_lds) top.stack[sp * kBvhLdsStackStride] = V2u{c, __float_as_uint(t)};

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             if (CX) {
                 CxHit ch;
                 int ci = -1;
-                key = cx_min_key(sc, BvhLds{nullptr, 0u, nullptr}, o, d, key, ch, ci);  // no LDS tree top in this kernel
+                key = cx_min_key(sc, BvhLds{nullptr, 0u, nullptr, 0u}, o, d, key, ch, ci);  // no LDS tree top in this kernel
                 if (ci >= 0) {
                     pre.valid = true;
                     pre.front = ch.ff != 0;

@@ -195,9 +195,10 @@ __global__ __launch_bounds__(kPinThreads, RT_PIN_WAVES) void pinhole_kernel(cons
     // the object index of a scan-path hit is only looked up when something reads it
     const bool need_obj = CX || sc.n_pl != 0 || p.first_id != nullptr;
     // scenes with meshes: the bottom of every lane's traversal stack (rt_complex.h mesh_first_hit)
-    __shared__ uint2 bvh_stack_all[CX && kBvhLdsStack ? kBvhLdsStack * kBvhLdsStackStride : 1];
+    constexpr unsigned kStack = CX ? (STREAM ? kBvhLdsStackStream : kBvhLdsStack) : 0u;
+    __shared__ uint2 bvh_stack_all[kStack ? kStack * kBvhLdsStackStride : 1];
     static_assert(kPinThreads == (int)kBvhLdsStackStride, "one stack column per thread of the block");
-    const BvhLds top{(LdsF4*)bvh_top, CX ? p.bvh_lds_nodes : 0u, CX && kBvhLdsStack ? (LdsU2*)bvh_stack_all + threadIdx.x : nullptr};
+    const BvhLds top{(LdsF4*)bvh_top, CX ? p.bvh_lds_nodes : 0u, kStack ? (LdsU2*)bvh_stack_all + threadIdx.x : nullptr, kStack};
     if (!STREAM || CX) __syncthreads();
 
     // per-wave ring of continuing rays (global memory, only this wave touches it)
